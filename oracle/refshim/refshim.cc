@@ -1,0 +1,178 @@
+// oracle/refshim/refshim.cc -- TEST INFRASTRUCTURE (oracle side), not product code.
+//
+// Flat C entry points onto the REAL reference libraries (libggml-base / libggml-cpu built by
+// oracle/Makefile from /root/reference sources into oracle/_ref/<variant>/).  Python tests and the
+// bench.py cpu_baseline leg load this through ctypes; nothing in the product path links it.
+//
+// Every function here just forwards to the public ggml API of the reference:
+//   type traits ............ ggml/include/ggml.h:2123-2133, ggml/include/ggml-cpu.h:112-119
+//   ggml_quantize_chunk .... ggml/src/ggml.c:6386-6450
+//   CPU mul_mat ............ ggml/src/ggml-cpu/ggml-cpu.c:1266-1458 (through ggml_graph_compute_with_ctx)
+//   CPU mul_mat_id ......... ggml/src/ggml-cpu/ggml-cpu.c:1540-1718
+#include <ggml.h>
+#include <ggml-cpu.h>
+#include <ggml-backend.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+// ggml fills its f16->f32 lookup table inside the first ggml_init() (ggml/src/ggml.c, ggml_init);
+// the scalar (non-F16C) build reads that table from every GGML_FP16_TO_FP32, so force it once.
+namespace {
+struct ref_static_init {
+    ref_static_init() {
+        struct ggml_init_params ip = { 1024, nullptr, false };
+        struct ggml_context * ctx = ggml_init(ip);
+        if (ctx) ggml_free(ctx);
+        ggml_cpu_init();
+    }
+} g_ref_static_init;
+}
+
+extern "C" {
+
+int64_t ref_blck_size(int type) { return ggml_blck_size((ggml_type) type); }
+int64_t ref_type_size(int type) { return (int64_t) ggml_type_size((ggml_type) type); }
+int64_t ref_row_size(int type, int64_t k) { return (int64_t) ggml_row_size((ggml_type) type, k); }
+const char * ref_type_name(int type) { return ggml_type_name((ggml_type) type); }
+int ref_vec_dot_type(int type) { ggml_cpu_init(); return (int) ggml_get_type_traits_cpu((ggml_type) type)->vec_dot_type; }
+int ref_requires_imatrix(int type) { return ggml_quantize_requires_imatrix((ggml_type) type) ? 1 : 0; }
+
+// f32 rows -> packed blocks of `type` (imatrix = all ones when the type demands one, as
+// tests/test-backend-ops.cpp:80-89 does).
+int64_t ref_quantize_chunk(int type, const float * src, void * dst, int64_t nrows, int64_t n_per_row) {
+    ggml_quantize_init((ggml_type) type);
+    std::vector<float> im;
+    const float * imatrix = nullptr;
+    if (ggml_quantize_requires_imatrix((ggml_type) type)) {
+        im.assign(n_per_row, 1.0f);
+        imatrix = im.data();
+    }
+    return (int64_t) ggml_quantize_chunk((ggml_type) type, src, dst, 0, nrows, n_per_row, imatrix);
+}
+
+// packed blocks -> f32 (the exact decode spec: dequantize_row_*, ggml-quants.c)
+void ref_dequantize_row(int type, const void * src, float * dst, int64_t k) {
+    ggml_get_type_traits((ggml_type) type)->to_float(src, dst, k);
+}
+
+// reference (scalar, deterministic) quantizer quantize_row_*_ref
+// (Q8_K has no from_float_ref in the base traits, ggml.c:788-793; its only quantizer is the CPU one,
+//  which forwards to quantize_row_q8_K_ref -- ggml-cpu-quants.c:1746)
+void ref_from_float_ref(int type, const float * x, void * y, int64_t k) {
+    ggml_from_float_t f = ggml_get_type_traits((ggml_type) type)->from_float_ref;
+    if (f) f(x, y, k);
+    else   ggml_get_type_traits_cpu((ggml_type) type)->from_float(x, y, k);
+}
+
+// the CPU backend's own activation quantizer (may be SIMD) for `type` (a vec_dot_type)
+void ref_from_float_cpu(int type, const float * x, void * y, int64_t k) {
+    ggml_cpu_init();
+    ggml_get_type_traits_cpu((ggml_type) type)->from_float(x, y, k);
+}
+
+// one row . one quantized activation row, the CPU hot loop (ggml-cpu.c:1176-1264 calls this)
+void ref_vec_dot(int type, int64_t n, float * s, const void * vx, const void * vy) {
+    ggml_cpu_init();
+    ggml_get_type_traits_cpu((ggml_type) type)->vec_dot((int) n, s, 0, vx, 0, vy, 0, 1);
+}
+
+// dst[M x N] (f32, row-major N rows of M) = W[M x K](type) . x[N rows of K] (f32)
+// through the real CPU backend op.  Returns 0 on success.
+int ref_mul_mat(int type, const void * W, const float * x, float * dst,
+                int64_t M, int64_t N, int64_t K, int n_threads) {
+    const size_t wbytes = ggml_row_size((ggml_type) type, K) * M;
+    const size_t mem = wbytes + (size_t) K * N * 4 + (size_t) M * N * 4 + (size_t) 64 * 1024 * 1024
+                     + (size_t) K * N * 8; // work buffer head-room (from_float scratch)
+    struct ggml_init_params ip = { mem, nullptr, false };
+    struct ggml_context * ctx = ggml_init(ip);
+    if (!ctx) return 1;
+    struct ggml_tensor * a = ggml_new_tensor_2d(ctx, (ggml_type) type, K, M);
+    struct ggml_tensor * b = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, K, N);
+    memcpy(a->data, W, wbytes);
+    memcpy(b->data, x, (size_t) K * N * 4);
+    struct ggml_tensor * c = ggml_mul_mat(ctx, a, b);
+    struct ggml_cgraph * gf = ggml_new_graph(ctx);
+    ggml_build_forward_expand(gf, c);
+    enum ggml_status st = ggml_graph_compute_with_ctx(ctx, gf, n_threads);
+    if (st == GGML_STATUS_SUCCESS) memcpy(dst, c->data, (size_t) M * N * 4);
+    ggml_free(ctx);
+    return st == GGML_STATUS_SUCCESS ? 0 : 2;
+}
+
+// dst[M, n_used, n_tok] = as[M x K x n_expert][ids] . b[K, nb1 (n_used or 1), n_tok]
+// ids i32 [n_used, n_tok].  (ggml.c:2771-2796 / ggml-cpu.c:1540-1718)
+int ref_mul_mat_id(int type, const void * as, const float * b, const int32_t * ids, float * dst,
+                   int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_tok, int64_t b_ne1,
+                   int n_threads) {
+    const size_t wbytes = ggml_row_size((ggml_type) type, K) * M * n_expert;
+    const size_t mem = wbytes + (size_t) K * b_ne1 * n_tok * 12 + (size_t) M * n_used * n_tok * 4
+                     + (size_t) 64 * 1024 * 1024;
+    struct ggml_init_params ip = { mem, nullptr, false };
+    struct ggml_context * ctx = ggml_init(ip);
+    if (!ctx) return 1;
+    struct ggml_tensor * a  = ggml_new_tensor_3d(ctx, (ggml_type) type, K, M, n_expert);
+    struct ggml_tensor * bb = ggml_new_tensor_3d(ctx, GGML_TYPE_F32, K, b_ne1, n_tok);
+    struct ggml_tensor * id = ggml_new_tensor_2d(ctx, GGML_TYPE_I32, n_used, n_tok);
+    memcpy(a->data, as, wbytes);
+    memcpy(bb->data, b, (size_t) K * b_ne1 * n_tok * 4);
+    memcpy(id->data, ids, (size_t) n_used * n_tok * 4);
+    struct ggml_tensor * c = ggml_mul_mat_id(ctx, a, bb, id);
+    struct ggml_cgraph * gf = ggml_new_graph(ctx);
+    ggml_build_forward_expand(gf, c);
+    enum ggml_status st = ggml_graph_compute_with_ctx(ctx, gf, n_threads);
+    if (st == GGML_STATUS_SUCCESS) memcpy(dst, c->data, (size_t) M * n_used * n_tok * 4);
+    ggml_free(ctx);
+    return st == GGML_STATUS_SUCCESS ? 0 : 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CPU baseline: a chain of independent quantized mul_mats (the per-token weight set of a model),
+// built ONCE as one ggml graph on the CPU backend, then computed `iters` times.  Returns seconds
+// per graph evaluation (mean), or <0 on error.  Weights are filled with a cheap LCG byte pattern
+// whose f16 scale fields are forced finite -- values do not matter for timing.
+// ---------------------------------------------------------------------------------------------
+static void fill_blocks(void * p, size_t nbytes, uint32_t seed) {
+    uint8_t * b = (uint8_t *) p;
+    uint32_t s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < nbytes; ++i) { s = s * 1664525u + 1013904223u; b[i] = (uint8_t)(s >> 24) & 0x3F; }
+}
+
+double ref_bench_chain(int n_mats, const int * types, const int64_t * Ms, const int64_t * Ks,
+                       int64_t N, int n_threads, int warmup, int iters) {
+    size_t mem = (size_t) 256 * 1024 * 1024;
+    for (int i = 0; i < n_mats; ++i) {
+        mem += ggml_row_size((ggml_type) types[i], Ks[i]) * Ms[i] + (size_t) Ks[i] * N * 4
+             + (size_t) Ms[i] * N * 4 + 4096;
+    }
+    struct ggml_init_params ip = { mem, nullptr, false };
+    struct ggml_context * ctx = ggml_init(ip);
+    if (!ctx) return -1.0;
+    struct ggml_cgraph * gf = ggml_new_graph_custom(ctx, n_mats + 16, false);
+    for (int i = 0; i < n_mats; ++i) {
+        struct ggml_tensor * a = ggml_new_tensor_2d(ctx, (ggml_type) types[i], Ks[i], Ms[i]);
+        struct ggml_tensor * b = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, Ks[i], N);
+        fill_blocks(a->data, ggml_nbytes(a), (uint32_t) i + 1);
+        float * bf = (float *) b->data;
+        for (int64_t j = 0; j < Ks[i] * N; ++j) bf[j] = (float)((j * 2654435761u >> 8) & 0xFFFF) / 65536.0f - 0.5f;
+        ggml_build_forward_expand(gf, ggml_mul_mat(ctx, a, b));
+    }
+    struct ggml_cplan plan = ggml_graph_plan(gf, n_threads, nullptr);
+    std::vector<uint8_t> work(plan.work_size + 64);
+    plan.work_data = work.data();
+    for (int w = 0; w < warmup; ++w) {
+        if (ggml_graph_compute(gf, &plan) != GGML_STATUS_SUCCESS) { ggml_free(ctx); return -2.0; }
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < iters; ++it) {
+        if (ggml_graph_compute(gf, &plan) != GGML_STATUS_SUCCESS) { ggml_free(ctx); return -2.0; }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    ggml_free(ctx);
+    return std::chrono::duration<double>(t1 - t0).count() / (iters > 0 ? iters : 1);
+}
+
+} // extern "C"
