@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- llama-bench tg128 on the quantized-matmul hot path, Llama-3-8B Q4_K_M, on MI355X.
+
+One "step" = one generated token = one pass over every quantized matmul weight the token touches
+(32 x {attn_q, attn_k, attn_v, attn_output, ffn_gate, ffn_up, ffn_down} + output: 225 matrices, 4.616 GB,
+BASELINE.md section 3), N=1 activation column, issued the way the backend issues them: 4 launches per layer
+(q/k/v fused, attn_output, gate/up fused, ffn_down) + 1, captured in a hipGraph.  Inputs (weights and
+activations) are resident in HBM before the timed region.  Non-matmul graph ops (norm, rope, attention,
+softmax...) are NOT part of this path and are not executed (they are the "next" rows).
+
+  python bench.py [--gpus N --steps K --warmup W]         (N>1: launched by torch.distributed.run)
+
+N>1 = the reference's --split-mode layer: contiguous layer ranges per GPU, the [1, n_embd] f32 activation
+handed to the next stage with an RCCL send/recv; a token visits the stages in order (strong scaling: the
+curve measures hop overhead).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "llama.cpp.dsp_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (6.3 TB/s measured achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)     # tg128
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--ftype", default="Q4_K_M", choices=["Q4_K_M", "Q8_0"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per matrix (no q/k/v, gate/up fusion)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing only (CPU/gloo test of the N>1 hop protocol): no GPU work")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------
+def device_random_weight(torch, g, spec, device):
+    """Random VALID packed rows generated on the device (random payload bytes, finite f16 scales),
+    then converted to the device layout with mi355q_weights_pack_d2d."""
+    bs = {g.Q4_K: 144, g.Q6_K: 210, g.Q8_0: 34}[spec.type]
+    blck = 32 if spec.type == g.Q8_0 else 256
+    nb = spec.K // blck
+    raw = torch.randint(0, 256, (spec.M, nb, bs), dtype=torch.uint8, device=device)
+    for off in {g.Q4_K: (0, 2), g.Q6_K: (208,), g.Q8_0: (0,)}[spec.type]:
+        sc = (torch.rand((spec.M, nb), device=device) * 0.02 + 1e-3).to(torch.float16)
+        raw[:, :, off:off + 2] = sc.view(torch.uint8).view(spec.M, nb, 2)
+    dst = torch.empty(spec.nbytes + 64, dtype=torch.uint8, device=device)
+    rc = g.lib().mi355q_weights_pack_d2d(spec.type, dst.data_ptr(), raw.data_ptr(), spec.M, spec.K,
+                                         int(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError(g.lib().mi355q_last_error().decode())
+    torch.cuda.synchronize()
+    return g.QWeight(spec.type, dst, spec.M, spec.K)
+
+
+class Stage:
+    """The layers (and possibly the output matrix) one rank owns, as a list of launch groups."""
+
+    def __init__(self, torch, g, specs, fuse, device):
+        self.torch, self.g = torch, g
+        self.groups = []         # (list[QWeight], x tensor, list[y tensors], nbytes)
+        self.bytes = 0
+        xs = {}
+        def x_for(k):
+            if k not in xs:
+                xs[k] = torch.randn((1, k), dtype=torch.float32, device=device)
+            return xs[k]
+        by_layer = {}
+        for s in specs:
+            by_layer.setdefault(s.layer, []).append(s)
+        for layer in sorted(by_layer, key=lambda l: (l < 0, l)):
+            ss = {s.name.split(".")[-1]: s for s in by_layer[layer]}
+            plan = [["attn_q", "attn_k", "attn_v"], ["attn_output"], ["ffn_gate", "ffn_up"], ["ffn_down"]] if layer >= 0 else [["output"]]
+            if not fuse:
+                plan = [[n] for grp in plan for n in grp]
+            for grp in plan:
+                ws = [device_random_weight(torch, g, ss[n], device) for n in grp]
+                ys = [torch.empty((1, w.M), dtype=torch.float32, device=device) for w in ws]
+                nbytes = sum(w.nbytes for w in ws)
+                self.groups.append((ws, x_for(ws[0].K), ys, nbytes))
+                self.bytes += nbytes
+
+    def run(self):
+        g = self.g
+        for ws, x, ys, _ in self.groups:
+            if len(ws) == 1:
+                g.mul_mat(ws[0], x, out=ys[0])
+            else:
+                g.mul_mat_multi(ws, x, outs=ys)
+
+
+def cpu_baseline(specs, seconds):
+    """The reference ggml CPU backend (oracle/_ref, compiled from /root/reference) on this host's cores:
+    the same 225-matmul token chain as ONE ggml graph, N=1."""
+    import oracle
+    variant = oracle.best_ref_variant()
+    if variant is None:
+        return None
+    ref = oracle.Reference(variant)
+    threads = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    types = [s.type for s in specs]; Ms = [s.M for s in specs]; Ks = [s.K for s in specs]
+    t1 = ref.bench_chain(types, Ms, Ks, 1, threads, 1, 1)
+    if t1 <= 0:
+        return None
+    iters = max(2, min(200, int(seconds / t1)))
+    t = ref.bench_chain(types, Ms, Ks, 1, threads, 1, iters)
+    return {"value": round(1.0 / t, 3), "unit": "tok/s", "cores": threads, "kind": "reference",
+            "sample": f"full token chain ({len(specs)} quantized mul_mats, N=1) as one ggml CPU graph, "
+                      f"{iters} evaluations, oracle/_ref/{variant} (ggml CPU backend built from the reference sources)"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    import torch
+    import torch.distributed as dist
+    import ggml_mi355 as g
+    from ggml_mi355 import workloads as wl
+
+    if a.dry_run:
+        device = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        g.lib()                                     # fail loudly if the HIP extension is missing
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
+
+    cfg = wl.LLAMA3_8B
+    specs = wl.llama_matmuls(cfg, a.ftype)
+    total_bytes = sum(s.nbytes for s in specs)
+    ranges = wl.partition_layers(cfg["n_layer"], world)
+    mine = [s for s in specs if s.layer in ranges[rank] or (s.layer < 0 and rank == world - 1)]
+
+    act = torch.zeros((1, cfg["n_embd"]), dtype=torch.float32, device=device)
+
+    if a.dry_run:
+        stage = None
+        def token():
+            if world > 1 and rank > 0:
+                dist.recv(act, src=rank - 1)
+            if world > 1 and rank < world - 1:
+                dist.send(act, dst=rank + 1)
+    else:
+        stage = Stage(torch, g, mine, not a.no_fuse, device)
+        graph = None
+        if not a.no_graph:
+            stage.run(); torch.cuda.synchronize()              # warm every kernel / attribute before capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                stage.run()
+        def token():
+            if world > 1 and rank > 0:
+                dist.recv(act, src=rank - 1)                    # boundary activation from the previous stage
+            graph.replay() if graph is not None else stage.run()
+            if world > 1 and rank < world - 1:
+                dist.send(act, dst=rank + 1)
+
+    def sync():
+        if not a.dry_run:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if not a.dry_run:
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        token()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        token()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out = {
+        "metric": "llama-bench tg128 tok/s (quantized-matmul hot path), Llama-3-8B " + a.ftype,
+        "value": round(a.steps / dt, 2), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "int8",
+        "data": "synthetic (random packed blocks with finite scales, gaussian activations)",
+        "config": {"workload": f"Llama-3-8B {a.ftype} tg (N=1): all {len(specs)} quantized mul_mat weights per token, "
+                               f"{total_bytes / 1e9:.3f} GB/token; {'fused q|k|v and gate|up launches, ' if not a.no_fuse else ''}"
+                               f"{'hipGraph replay' if not a.no_graph else 'eager launches'}; non-matmul graph ops not executed",
+                   "bytes_per_token": total_bytes,
+                   "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs (RCCL send/recv of the boundary activation)"},
+    }
+
+    if not a.dry_run and rank == 0:
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ----
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stage.groups]
+        reps = 5
+        per_kernel = {}
+        for rep in range(reps + 1):
+            for (ws, x, ys, nbytes), (e0, e1) in zip(stage.groups, ev):
+                e0.record()
+                if len(ws) == 1: g.mul_mat(ws[0], x, out=ys[0])
+                else: g.mul_mat_multi(ws, x, outs=ys)
+                e1.record()
+            torch.cuda.synchronize()
+            if rep == 0:
+                continue                                       # first pass = warm-up
+            for (ws, x, ys, nbytes), (e0, e1) in zip(stage.groups, ev):
+                u = 2 if ws[0].K <= 128 * 64 else 4            # chunk loads in flight per lane chosen by the launcher
+                name = f"k_gemv_fast<Q8_K family, ncols=1, U={u}> (K={ws[0].K})"
+                acc = per_kernel.setdefault(name, [0, 0.0, 0])
+                acc[0] += nbytes; acc[1] += e0.elapsed_time(e1) * 1e-3; acc[2] += 1
+        dom = max(per_kernel.items(), key=lambda kv: kv[1][0])
+        nbytes, secs, launches = dom[1]
+        achieved = nbytes / secs / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "kernel": dom[0], "launches_per_token": launches // reps,
+                           "algorithmic_bytes_per_launch": nbytes // launches,
+                           "avg_launch_us": round(1e6 * secs / launches, 2),
+                           "whole_token_GBps": round(total_bytes * a.steps / dt / 1e9, 1) if world == 1 else None,
+                           "all_kernels": {k: {"GBps": round(v[0] / v[1] / 1e9, 1), "avg_us": round(1e6 * v[1] / v[2], 2),
+                                               "launches_per_token": v[2] // reps} for k, v in per_kernel.items()}}
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(specs, a.cpu_seconds)
+            except Exception as e:                              # the baseline is a report, never a reason to fail the bench
+                out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

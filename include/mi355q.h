@@ -1,0 +1,171 @@
+/* mi355q.h -- C-ABI of libmi355q.so: MI355X (gfx950 / CDNA4) kernels for the quantized
+ * dequant + mat-vec / mat-mat multiply that dominates llama.cpp token generation.
+ *
+ * This is the drop-in boundary for the hot path.  Plain pointers and sizes only; no ggml, torch
+ * or HIP types appear in any signature (streams are passed as void* = hipStream_t).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *
+ *   mi355q_mul_mat        GGML_OP_MUL_MAT with quantized src0, f32 src1, f32 dst
+ *                           CPU : ggml_compute_forward_mul_mat      ggml/src/ggml-cpu/ggml-cpu.c:1266-1458
+ *                           GPU : ggml_cuda_mul_mat -> mul_mat_vec_q / mul_mat_q / dequant+GEMM
+ *                                 ggml/src/ggml-cuda/ggml-cuda.cu:1877-1938, mmvq.cu:130-288, mmq.cuh:2595-2674
+ *   mi355q_mul_mat_id     GGML_OP_MUL_MAT_ID (MoE expert-indirect matmul)
+ *                           CPU : ggml_compute_forward_mul_mat_id   ggml/src/ggml-cpu/ggml-cpu.c:1540-1718
+ *                           GPU : ggml_cuda_mul_mat_id              ggml/src/ggml-cuda/ggml-cuda.cu:1994-2130
+ *   mi355q_quantize_act   activation quantizer run before every quantized matmul
+ *                           CPU : from_float of the vec_dot_type    ggml/src/ggml-cpu/ggml-cpu.c:1328-1363,
+ *                                 quantize_row_q8_0/q8_1/q8_K       ggml/src/ggml-quants.c:194-253, 2479-2516
+ *                           GPU : quantize_q8_1                     ggml/src/ggml-cuda/quantize.cu:4-38
+ *   mi355q_weights_upload / _download
+ *                         ggml_backend_buffer_i.set_tensor / get_tensor for quantized weights
+ *                           ggml/src/ggml-backend-impl.h:41-66 (CUDA: ggml-cuda.cu:568-600); the device keeps a
+ *                           coalescing-friendly per-row plane layout, invisible above this ABI
+ *   mi355q_row_size / mi355q_type_supported
+ *                         ggml_row_size / ggml_backend_device_i.supports_op
+ *                           ggml/src/ggml.c (ggml_row_size), ggml/src/ggml-backend-impl.h:137-185
+ *
+ * The ggml backend plugin (libggml-mi355.so: ggml_backend_init / ggml_backend_score, the four vtables of
+ * ggml/src/ggml-backend-impl.h) is a thin C++ host layer over this ABI; see INTEGRATION.md.
+ *
+ * Numerics contract: activations are quantized exactly as the reference CPU backend does for the weight
+ * type (Q8_0 / Q8_1 for the 32-element formats, Q8_K for K-quants and IQ4_XS), every per-block integer dot
+ * product is exact, and only the order of the final f32 additions differs from the CPU.
+ *
+ * All functions return 0 on success, a negative MI355Q_ERR_* otherwise (never throw, never abort).
+ * A missing / non-gfx950 device is an error, not a fallback: there is no CPU path in this library.
+ */
+#ifndef MI355Q_H
+#define MI355Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355Q_API_VERSION 1
+
+/* error codes */
+#define MI355Q_OK                0
+#define MI355Q_ERR_UNSUPPORTED  -1   /* type / shape combination not implemented            */
+#define MI355Q_ERR_SHAPE        -2   /* inconsistent sizes, K not a multiple of the block   */
+#define MI355Q_ERR_ALIGN        -3   /* pointer / stride alignment contract violated        */
+#define MI355Q_ERR_HIP          -4   /* a HIP runtime call failed (see mi355q_last_error)   */
+#define MI355Q_ERR_WORKSPACE    -5   /* workspace too small                                 */
+#define MI355Q_ERR_NO_DEVICE    -6   /* no usable gfx950 device                             */
+
+/* weight / activation type ids are ggml's enum ggml_type values (ggml/include/ggml.h) */
+#define MI355Q_TYPE_F32    0
+#define MI355Q_TYPE_Q4_0   2
+#define MI355Q_TYPE_Q4_1   3
+#define MI355Q_TYPE_Q5_0   6
+#define MI355Q_TYPE_Q5_1   7
+#define MI355Q_TYPE_Q8_0   8
+#define MI355Q_TYPE_Q8_1   9
+#define MI355Q_TYPE_Q2_K   10
+#define MI355Q_TYPE_Q3_K   11
+#define MI355Q_TYPE_Q4_K   12
+#define MI355Q_TYPE_Q5_K   13
+#define MI355Q_TYPE_Q6_K   14
+#define MI355Q_TYPE_Q8_K   15
+#define MI355Q_TYPE_IQ4_NL 20
+#define MI355Q_TYPE_IQ4_XS 23
+
+/* flags for mi355q_mul_mat* / mi355q_quantize_act */
+#define MI355Q_FLAG_ROUND_AWAY   0x0  /* Q8_0/Q8_1 activations: q = roundf(x/d)   (quantize_row_q8_0_ref; default) */
+#define MI355Q_FLAG_ROUND_EVEN   0x1  /*                        q = rint(x/d)     (what the AVX2 / NEON CPU paths do) */
+#define MI355Q_FLAG_FORCE_GENERIC 0x2 /* debugging: use the generic (canonical-layout-style) kernel tier            */
+#define MI355Q_FLAG_FORCE_GEMV   0x4  /* use the GEMV tier even for large N                                         */
+#define MI355Q_FLAG_FORCE_MMQ    0x8  /* use the tiled MFMA tier even for small N                                   */
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int          mi355q_api_version(void);
+int          mi355q_device_count(void);                 /* number of visible gfx950 devices (0 if none)   */
+int          mi355q_set_device(int device);
+int          mi355q_device_info(int device, char *name, size_t name_len, size_t *free_bytes, size_t *total_bytes,
+                                int *compute_units);
+const char * mi355q_last_error(void);                   /* thread-local description of the last failure   */
+
+/* ---- geometry ------------------------------------------------------------------------------------ */
+int     mi355q_type_supported(int type);                /* 1 if `type` is accepted as src0 of mul_mat      */
+int64_t mi355q_blck_size(int type);
+int64_t mi355q_type_size(int type);
+int64_t mi355q_row_size(int type, int64_t k);           /* == ggml_row_size(type, k); device rows use the same size */
+int     mi355q_act_type(int type);                      /* activation format paired with `type` (CPU's vec_dot_type) */
+int     mi355q_weights_are_planar(int type, int64_t k); /* 1 if device rows of (type,k) use the plane layout */
+
+/* ---- thin device-memory helpers (so hosts without a HIP binding can drive the library) ----------- */
+int mi355q_malloc(void **dev_ptr, size_t bytes);
+int mi355q_free(void *dev_ptr);
+int mi355q_memset(void *dev_ptr, int value, size_t bytes, void *stream);
+int mi355q_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);   /* stream NULL: synchronous */
+int mi355q_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int mi355q_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int mi355q_stream_create(void **stream);
+int mi355q_stream_destroy(void *stream);
+int mi355q_stream_synchronize(void *stream);
+int mi355q_device_synchronize(void);
+
+/* ---- weights: canonical ggml rows <-> device rows -------------------------------------------------
+ * `nrows` whole rows of `k` elements each.  Device rows have the same byte size and row stride as
+ * canonical rows (so row-granular views and MoE expert offsets stay valid); only the order of bytes
+ * INSIDE a row changes when mi355q_weights_are_planar(type,k).  dst/src device pointers must be
+ * 16-byte aligned.  `stream` may be NULL (default stream); the call returns after the copy is complete. */
+int mi355q_weights_upload(int type, void *dst_dev, const void *src_host, int64_t nrows, int64_t k, void *stream);
+int mi355q_weights_download(int type, void *dst_host, const void *src_dev, int64_t nrows, int64_t k, void *stream);
+/* device-to-device variants (canonical bytes already on the device <-> device rows) */
+int mi355q_weights_pack_d2d(int type, void *dst_dev, const void *src_canonical_dev, int64_t nrows, int64_t k, void *stream);
+int mi355q_weights_unpack_d2d(int type, void *dst_canonical_dev, const void *src_dev, int64_t nrows, int64_t k, void *stream);
+
+/* ---- activation quantizer --------------------------------------------------------------------------
+ * x: f32 device, `n` rows of `k` elements, row stride x_stride_bytes (multiple of 4).
+ * out: device, n * mi355q_row_size(act_type,k) bytes, CANONICAL ggml block structs
+ *      (block_q8_0 / block_q8_1 / block_q8_K, ggml-common.h:209-227, 329-334), bit-identical to the CPU. */
+int mi355q_quantize_act(int act_type, const float *x, int64_t x_stride_bytes, void *out,
+                        int64_t n, int64_t k, int flags, void *stream);
+
+/* ---- MUL_MAT -----------------------------------------------------------------------------------------
+ * y[n][m] = sum_k W[m][k] * x[n][k]       W: `m` device rows of type `type` (uploaded with
+ * mi355q_weights_upload), row stride w_stride_bytes (>= row_size, multiple of 16);
+ * x: f32 [n rows of k], row stride x_stride_bytes;  y: f32 [n rows of m], row stride y_stride_bytes.
+ * workspace: device scratch of at least mi355q_mul_mat_workspace(type,m,n,k) bytes (may be NULL if 0). */
+size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k);
+int    mi355q_mul_mat(int type, const void *w, int64_t w_stride_bytes,
+                      const float *x, int64_t x_stride_bytes,
+                      float *y, int64_t y_stride_bytes,
+                      int64_t m, int64_t n, int64_t k,
+                      void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+/* Several weight matrices against the SAME activations in one launch (wq/wk/wv, ffn_gate/ffn_up):
+ * y_i[n][m_i] = W_i . x.  All W_i share type-independent k and n; types may differ per matrix.  */
+typedef struct mi355q_mat {
+    int         type;
+    const void *w;
+    int64_t     w_stride;   /* bytes between weight rows (>= row_size, multiple of 16 for planar rows) */
+    float      *y;
+    int64_t     y_stride;   /* bytes between output rows (one per activation row)                      */
+    int64_t     m;
+} mi355q_mat;
+int    mi355q_mul_mat_multi(const mi355q_mat *mats, int n_mats,
+                            const float *x, int64_t x_stride_bytes, int64_t n, int64_t k,
+                            void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+/* ---- MUL_MAT_ID ---------------------------------------------------------------------------------------
+ * y[t][u][:] = W[ids[t][u]] . x[t][u % x_ne1][:]
+ * w: n_expert consecutive matrices of m device rows each (expert stride = expert_stride_bytes);
+ * x: f32 [n_tok][x_ne1][k] contiguous rows with strides x_stride1_bytes (slot) and x_stride2_bytes (token);
+ * ids: i32 device [n_tok][n_used] with row stride ids_stride_bytes;  y: f32 [n_tok][n_used][m] contiguous.
+ * The expert ids are read ON THE DEVICE (no host round trip, cf. ggml-cuda.cu:2008-2011). */
+size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1);
+int    mi355q_mul_mat_id(int type, const void *w, int64_t w_stride_bytes, int64_t expert_stride_bytes, int64_t n_expert,
+                         const float *x, int64_t x_ne1, int64_t x_stride1_bytes, int64_t x_stride2_bytes,
+                         const int32_t *ids, int64_t ids_stride_bytes,
+                         float *y, int64_t m, int64_t k, int64_t n_used, int64_t n_tok,
+                         void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355Q_H */

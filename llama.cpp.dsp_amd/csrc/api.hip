@@ -1,0 +1,282 @@
+// api.hip -- the C-ABI of libmi355q.so (include/mi355q.h): argument checking, tier dispatch, thin
+// HIP memory helpers.  No ggml, no torch.  Every entry point returns an MI355Q_* code.
+#include "mi355q_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace mi355q {
+// kernels (other translation units)
+int launch_quantize_act(int act_type, const float * x, int64_t x_stride, void * out, int64_t n, int64_t k, int flags, hipStream_t stream);
+struct GenericMoe { const int32_t * ids; int64_t ids_stride; int64_t expert_stride; int n_used; int x_ne1; int n_expert; int pad; };
+int launch_gemv_generic(int type, const void * w, int64_t w_stride, const void * act, int64_t act_stride,
+                        float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, hipStream_t stream, const GenericMoe * moe);
+struct MoeArgs { const int32_t * ids; int64_t ids_stride; int64_t expert_stride; int64_t x_stride2; int n_used; int x_ne1; int n_expert; int n_pairs; };
+int launch_gemv_fast(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int ncols, int64_t k,
+                     int flags, int n_cu, hipStream_t stream, const MoeArgs * moe);
+int gemv_fast_family(int type);
+int gemv_fast_max_cols(int type, int64_t k);
+int launch_pack(int type, void * dst, const void * src, int64_t nrows, int64_t k, bool pack, hipStream_t stream);
+
+static thread_local char t_err[512] = "";
+static int fail(int code, const char * fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(t_err, sizeof(t_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MI355Q_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+#define MQ_TRY(expr)  do { int r_ = (expr); if (r_ != MI355Q_OK) { if (!t_err[0]) fail(r_, "%s failed (%d)", #expr, r_); return r_; } } while (0)
+
+static int cu_count() {
+    static int cached[64]; static bool have[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!have[dev]) {
+        hipDeviceProp_t p;
+        cached[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256;
+        have[dev] = true;
+    }
+    return cached[dev];
+}
+} // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" {
+
+int mi355q_api_version(void) { return MI355Q_API_VERSION; }
+const char * mi355q_last_error(void) { return t_err; }
+
+int mi355q_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok == n ? n : 0;      // all visible devices must be gfx950: the code objects are built for it only
+}
+
+int mi355q_set_device(int device) { HIP_TRY(hipSetDevice(device)); return MI355Q_OK; }
+
+int mi355q_device_info(int device, char * name, size_t name_len, size_t * free_bytes, size_t * total_bytes, int * compute_units) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (free_bytes || total_bytes) {
+        int cur = 0; HIP_TRY(hipGetDevice(&cur)); HIP_TRY(hipSetDevice(device));
+        size_t f = 0, t = 0; HIP_TRY(hipMemGetInfo(&f, &t)); HIP_TRY(hipSetDevice(cur));
+        if (free_bytes) *free_bytes = f;
+        if (total_bytes) *total_bytes = t;
+    }
+    return MI355Q_OK;
+}
+
+int     mi355q_type_supported(int type) { const TypeInfo * t = type_info(type); return t && t->act >= 0; }
+int64_t mi355q_blck_size(int type) { const TypeInfo * t = type_info(type); return t ? t->blck : 0; }
+int64_t mi355q_type_size(int type) { const TypeInfo * t = type_info(type); return t ? t->bsize : 0; }
+int64_t mi355q_row_size(int type, int64_t k) { const TypeInfo * t = type_info(type); return t && k % t->blck == 0 ? k / t->blck * t->bsize : 0; }
+int     mi355q_act_type(int type) { const TypeInfo * t = type_info(type); return t ? t->act : -1; }
+int     mi355q_weights_are_planar(int type, int64_t k) { return is_planar(type_info(type), k) ? 1 : 0; }
+
+// ---- memory helpers ----
+int mi355q_malloc(void ** p, size_t bytes) { HIP_TRY(hipMalloc(p, bytes)); return MI355Q_OK; }
+int mi355q_free(void * p) { HIP_TRY(hipFree(p)); return MI355Q_OK; }
+int mi355q_memset(void * p, int v, size_t bytes, void * stream) { HIP_TRY(hipMemsetAsync(p, v, bytes, (hipStream_t) stream)); return MI355Q_OK; }
+static int copy(void * dst, const void * src, size_t bytes, hipMemcpyKind kind, void * stream) {
+    if (stream) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t) stream)); }
+    else        { HIP_TRY(hipMemcpy(dst, src, bytes, kind)); }
+    return MI355Q_OK;
+}
+int mi355q_memcpy_h2d(void * d, const void * s, size_t n, void * st) { return copy(d, s, n, hipMemcpyHostToDevice, st); }
+int mi355q_memcpy_d2h(void * d, const void * s, size_t n, void * st) { return copy(d, s, n, hipMemcpyDeviceToHost, st); }
+int mi355q_memcpy_d2d(void * d, const void * s, size_t n, void * st) { return copy(d, s, n, hipMemcpyDeviceToDevice, st); }
+int mi355q_stream_create(void ** s) { hipStream_t h; HIP_TRY(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = h; return MI355Q_OK; }
+int mi355q_stream_destroy(void * s) { HIP_TRY(hipStreamDestroy((hipStream_t) s)); return MI355Q_OK; }
+int mi355q_stream_synchronize(void * s) { HIP_TRY(hipStreamSynchronize((hipStream_t) s)); return MI355Q_OK; }
+int mi355q_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return MI355Q_OK; }
+
+// ---- weights ----
+static int check_rows(int type, int64_t nrows, int64_t k, const void * dev) {
+    const TypeInfo * t = type_info(type);
+    if (!t || t->act < 0) return fail(MI355Q_ERR_UNSUPPORTED, "type %d is not a supported weight type", type);
+    if (nrows < 0 || k <= 0 || k % t->blck) return fail(MI355Q_ERR_SHAPE, "k=%lld is not a multiple of the %d-element block", (long long) k, t->blck);
+    if (is_planar(t, k) && ((uintptr_t) dev & 15)) return fail(MI355Q_ERR_ALIGN, "device rows must be 16-byte aligned");
+    return MI355Q_OK;
+}
+
+int mi355q_weights_pack_d2d(int type, void * dst, const void * src, int64_t nrows, int64_t k, void * stream) {
+    MQ_TRY(check_rows(type, nrows, k, dst));
+    return launch_pack(type, dst, src, nrows, k, true, (hipStream_t) stream);
+}
+int mi355q_weights_unpack_d2d(int type, void * dst, const void * src, int64_t nrows, int64_t k, void * stream) {
+    MQ_TRY(check_rows(type, nrows, k, src));
+    return launch_pack(type, dst, src, nrows, k, false, (hipStream_t) stream);
+}
+
+static int staged_copy(int type, void * dev, void * host, int64_t nrows, int64_t k, bool upload, hipStream_t stream) {
+    MQ_TRY(check_rows(type, nrows, k, dev));
+    const int64_t rb = mi355q_row_size(type, k);
+    if (nrows == 0) return MI355Q_OK;
+    if (!is_planar(type_info(type), k)) {
+        if (upload) { HIP_TRY(hipMemcpyAsync(dev, host, (size_t) (rb * nrows), hipMemcpyHostToDevice, stream)); }
+        else        { HIP_TRY(hipMemcpyAsync(host, dev, (size_t) (rb * nrows), hipMemcpyDeviceToHost, stream)); }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MI355Q_OK;
+    }
+    int64_t chunk_rows = (int64_t) (64u << 20) / rb; if (chunk_rows < 1) chunk_rows = 1; if (chunk_rows > nrows) chunk_rows = nrows;
+    void * tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t) (chunk_rows * rb)));
+    int rc = MI355Q_OK;
+    for (int64_t r0 = 0; r0 < nrows && rc == MI355Q_OK; r0 += chunk_rows) {
+        const int64_t nr = nrows - r0 < chunk_rows ? nrows - r0 : chunk_rows;
+        char * d = (char *) dev + r0 * rb; char * h = (char *) host + r0 * rb;
+        hipError_t e;
+        if (upload) {
+            e = hipMemcpyAsync(tmp, h, (size_t) (nr * rb), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) rc = launch_pack(type, d, tmp, nr, k, true, stream);
+        } else {
+            rc = launch_pack(type, tmp, d, nr, k, false, stream);
+            e = rc == MI355Q_OK ? hipMemcpyAsync(h, tmp, (size_t) (nr * rb), hipMemcpyDeviceToHost, stream) : hipSuccess;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);       // tmp is reused by the next chunk
+        if (e != hipSuccess) rc = fail(MI355Q_ERR_HIP, "staged weight copy: %s", hipGetErrorString(e));
+    }
+    (void) hipFree(tmp);
+    return rc;
+}
+int mi355q_weights_upload(int type, void * dst_dev, const void * src_host, int64_t nrows, int64_t k, void * stream) {
+    return staged_copy(type, dst_dev, (void *) src_host, nrows, k, true, (hipStream_t) stream);
+}
+int mi355q_weights_download(int type, void * dst_host, const void * src_dev, int64_t nrows, int64_t k, void * stream) {
+    return staged_copy(type, (void *) src_dev, dst_host, nrows, k, false, (hipStream_t) stream);
+}
+
+// ---- activation quantizer ----
+int mi355q_quantize_act(int act_type, const float * x, int64_t x_stride_bytes, void * out, int64_t n, int64_t k, int flags, void * stream) {
+    if (x_stride_bytes % 4 || ((uintptr_t) x & 3) || ((uintptr_t) out & 3)) return fail(MI355Q_ERR_ALIGN, "quantize_act: 4-byte alignment required");
+    if (n > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "quantize_act: n > 65535");
+    const int rc = launch_quantize_act(act_type, x, x_stride_bytes, out, n, k, flags, (hipStream_t) stream);
+    return rc == MI355Q_OK ? rc : fail(rc, "quantize_act(act=%d,n=%lld,k=%lld) failed", act_type, (long long) n, (long long) k);
+}
+
+// ---- MUL_MAT ----
+static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t) 255; }
+
+size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k) {
+    (void) m;
+    const TypeInfo * t = type_info(type);
+    if (!t || t->act < 0 || k % t->blck) return 0;
+    if (is_planar(t, k)) return 0;                                    // fused prologue: no scratch
+    return (size_t) align256(mi355q_row_size(t->act, k) * n);
+}
+
+static int mul_mat_checks(const TypeInfo * t, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
+                          float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k) {
+    if (!t || t->act < 0) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat: unsupported weight type");
+    if (m < 0 || n < 0 || k <= 0 || k % t->blck) return fail(MI355Q_ERR_SHAPE, "mul_mat: bad shape m=%lld n=%lld k=%lld", (long long) m, (long long) n, (long long) k);
+    if (k > (1 << 20)) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat: k too large");
+    const int64_t rb = k / t->blck * t->bsize;
+    if (w_stride < rb) return fail(MI355Q_ERR_SHAPE, "mul_mat: w_stride < row size");
+    if (x_stride < 4 * k || x_stride % 4 || y_stride < 4 * m || y_stride % 4) return fail(MI355Q_ERR_SHAPE, "mul_mat: bad x/y stride");
+    if (((uintptr_t) x & 3) || ((uintptr_t) y & 3)) return fail(MI355Q_ERR_ALIGN, "mul_mat: x/y must be 4-byte aligned");
+    if ((m > 0 && n > 0) && (!w || !x || !y)) return fail(MI355Q_ERR_SHAPE, "mul_mat: null pointer");
+    return MI355Q_OK;
+}
+
+int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
+                         void * workspace, size_t workspace_bytes, int flags, void * stream) {
+    t_err[0] = 0;
+    if (n_mats <= 0) return MI355Q_OK;
+    hipStream_t st = (hipStream_t) stream;
+    bool all_fast = n_mats <= 4;
+    int fam = -1;
+    for (int i = 0; i < n_mats; ++i) {
+        const TypeInfo * t = type_info(mats[i].type);
+        MQ_TRY(mul_mat_checks(t, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k));
+        const bool planar = is_planar(t, k);
+        if (planar && (((uintptr_t) mats[i].w | (uintptr_t) mats[i].w_stride) & 15)) return fail(MI355Q_ERR_ALIGN, "mul_mat: planar rows need 16-byte aligned w / w_stride");
+        const int f = planar ? gemv_fast_family(mats[i].type) : -1;
+        if (f < 0 || (fam >= 0 && f != fam)) all_fast = false;
+        if (fam < 0) fam = f;
+    }
+    if (n == 0) return MI355Q_OK;
+    if (all_fast) {
+        // GEMV tier, tiled over activation columns (each tile re-streams W; the MFMA tier takes over for large n)
+        const int maxc = gemv_fast_max_cols(mats[0].type, k);
+        if (maxc < 1) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat: k=%lld does not fit the LDS activation image", (long long) k);
+        mi355q_mat tile[4];
+        for (int64_t n0 = 0; n0 < n; n0 += maxc) {
+            const int nc = (int) (n - n0 < maxc ? n - n0 : maxc);
+            for (int i = 0; i < n_mats; ++i) { tile[i] = mats[i]; tile[i].y = (float *) ((char *) mats[i].y + n0 * mats[i].y_stride); }
+            MQ_TRY(launch_gemv_fast(tile, n_mats, (const float *) ((const char *) x + n0 * x_stride), x_stride, nc, k, flags, cu_count(), st, nullptr));
+        }
+        return MI355Q_OK;
+    }
+    // mixed / non-planar: one matrix at a time
+    for (int i = 0; i < n_mats; ++i) {
+        const TypeInfo * t = type_info(mats[i].type);
+        if (is_planar(t, k)) {
+            MQ_TRY(mi355q_mul_mat_multi(&mats[i], 1, x, x_stride, n, k, workspace, workspace_bytes, flags, stream));
+            continue;
+        }
+        const int64_t arow = mi355q_row_size(t->act, k);
+        if (!workspace || workspace_bytes < (size_t) (arow * n)) return fail(MI355Q_ERR_WORKSPACE, "mul_mat: workspace %zu < %lld", workspace_bytes, (long long) (arow * n));
+        if (n > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat: n > 65535 on the generic tier");
+        MQ_TRY(launch_quantize_act(t->act, x, x_stride, workspace, n, k, flags, st));
+        MQ_TRY(launch_gemv_generic(mats[i].type, mats[i].w, mats[i].w_stride, workspace, arow, mats[i].y, mats[i].y_stride, mats[i].m, n, k, st, nullptr));
+    }
+    return MI355Q_OK;
+}
+
+int mi355q_mul_mat(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
+                   int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int flags, void * stream) {
+    mi355q_mat mt = { type, w, w_stride, y, y_stride, m };
+    return mi355q_mul_mat_multi(&mt, 1, x, x_stride, n, k, workspace, workspace_bytes, flags, stream);
+}
+
+// ---- MUL_MAT_ID ----
+size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1) {
+    (void) m; (void) n_used;
+    const TypeInfo * t = type_info(type);
+    if (!t || t->act < 0 || k % t->blck) return 0;
+    if (is_planar(t, k)) return 0;
+    return (size_t) align256(mi355q_row_size(t->act, k) * n_tok * x_ne1);
+}
+
+int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert_stride, int64_t n_expert,
+                      const float * x, int64_t x_ne1, int64_t x_stride1, int64_t x_stride2,
+                      const int32_t * ids, int64_t ids_stride, float * y, int64_t m, int64_t k, int64_t n_used, int64_t n_tok,
+                      void * workspace, size_t workspace_bytes, int flags, void * stream) {
+    t_err[0] = 0;
+    const TypeInfo * t = type_info(type);
+    MQ_TRY(mul_mat_checks(t, w, w_stride, x, x_stride1, y, 4 * m, m, n_used * n_tok, k));
+    if (!ids || n_expert <= 0 || x_ne1 <= 0 || (x_ne1 != 1 && x_ne1 != n_used && n_used % x_ne1)) return fail(MI355Q_ERR_SHAPE, "mul_mat_id: bad ids / x_ne1");
+    if (ids_stride % 4 || x_stride2 % 4) return fail(MI355Q_ERR_ALIGN, "mul_mat_id: strides must be multiples of 4");
+    const int64_t pairs = n_used * n_tok;
+    if (pairs == 0 || m == 0) return MI355Q_OK;
+    if (pairs > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat_id: more than 65535 (token,slot) pairs per call");
+    hipStream_t st = (hipStream_t) stream;
+    if (is_planar(t, k) && gemv_fast_family(type) >= 0) {
+        if (((uintptr_t) w | (uintptr_t) w_stride | (uintptr_t) expert_stride) & 15) return fail(MI355Q_ERR_ALIGN, "mul_mat_id: planar rows need 16-byte alignment");
+        mi355q_mat mt = { type, w, w_stride, y, 4 * m, m };
+        MoeArgs moe = { ids, ids_stride, expert_stride, x_stride2, (int) n_used, (int) x_ne1, (int) n_expert, (int) pairs };
+        MQ_TRY(launch_gemv_fast(&mt, 1, x, x_stride1, 1, k, flags, cu_count(), st, &moe));
+        return MI355Q_OK;
+    }
+    // generic tier: quantize all n_tok*x_ne1 activation rows, then one wave per (pair, row)
+    const int64_t arow = mi355q_row_size(t->act, k);
+    if (!workspace || workspace_bytes < (size_t) (arow * n_tok * x_ne1)) return fail(MI355Q_ERR_WORKSPACE, "mul_mat_id: workspace too small");
+    for (int64_t tk = 0; tk < n_tok; ++tk) {        // token planes may be strided: quantize plane by plane
+        MQ_TRY(launch_quantize_act(t->act, (const float *) ((const char *) x + tk * x_stride2), x_stride1,
+                                   (char *) workspace + tk * x_ne1 * arow, x_ne1, k, flags, st));
+    }
+    GenericMoe gm = { ids, ids_stride, expert_stride, (int) n_used, (int) x_ne1, (int) n_expert, 0 };
+    MQ_TRY(launch_gemv_generic(type, w, w_stride, workspace, arow, y, 4 * m, m, pairs, k, st, &gm));
+    return MI355Q_OK;
+}
+
+} // extern "C"

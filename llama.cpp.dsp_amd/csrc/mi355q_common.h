@@ -1,0 +1,127 @@
+// mi355q_common.h -- shared host/device definitions for libmi355q (gfx950 only).
+//
+// Block byte layouts follow the reference's format spec, ggml/src/ggml-common.h:167-418
+// (SURVEY.md 8a rows a1-a7).  Nothing here is taken from ggml-cuda: the device layout, the lane
+// mappings and the kernels are designed for 64-wide wavefronts and 16-byte-per-lane global loads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/mi355q.h"
+
+namespace mi355q {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------------
+// Type table.  A canonical ggml block of `bsize` bytes is cut into up to 4 "planes"
+// (byte ranges).  In the PLANAR device layout a row of nb blocks stores plane 0 of all nb blocks,
+// then plane 1 of all blocks, ... so that every plane is a dense, 16-byte-aligned array a wave can
+// read with one global_load_dwordx4 per lane.  Row byte size and row stride equal the canonical ones.
+// ------------------------------------------------------------------------------------------------
+struct Plane { int src_off; int bytes; };
+
+struct TypeInfo {
+    int   type;        // ggml type id
+    int   blck;        // elements per block
+    int   bsize;       // bytes per block
+    int   act;         // activation format the CPU pairs with it (vec_dot_type, ggml-cpu.c:211-376)
+    int   nplanes;
+    Plane planes[4];   // device order
+    int   fast;        // 1: a planar GEMV kernel exists
+};
+
+inline const TypeInfo * type_info(int type) {   // host only
+    // planes: payload first (always 16-B aligned for a 16-B aligned row), small fields after
+    static const TypeInfo tab[] = {
+        { MI355Q_TYPE_Q4_0,   32,  18, MI355Q_TYPE_Q8_0, 2, {{2, 16}, {0, 2}, {0, 0}, {0, 0}},            1 },
+        { MI355Q_TYPE_Q4_1,   32,  20, MI355Q_TYPE_Q8_1, 2, {{4, 16}, {0, 4}, {0, 0}, {0, 0}},            0 },
+        { MI355Q_TYPE_Q5_0,   32,  22, MI355Q_TYPE_Q8_0, 3, {{6, 16}, {2, 4}, {0, 2}, {0, 0}},            0 },
+        { MI355Q_TYPE_Q5_1,   32,  24, MI355Q_TYPE_Q8_1, 3, {{8, 16}, {4, 4}, {0, 4}, {0, 0}},            0 },
+        { MI355Q_TYPE_Q8_0,   32,  34, MI355Q_TYPE_Q8_0, 2, {{2, 32}, {0, 2}, {0, 0}, {0, 0}},            1 },
+        { MI355Q_TYPE_Q2_K,   256, 84, MI355Q_TYPE_Q8_K, 3, {{16, 64}, {0, 16}, {80, 4}, {0, 0}},         0 },
+        { MI355Q_TYPE_Q3_K,   256, 110, MI355Q_TYPE_Q8_K, 4, {{32, 64}, {0, 32}, {96, 12}, {108, 2}},     0 },
+        { MI355Q_TYPE_Q4_K,   256, 144, MI355Q_TYPE_Q8_K, 2, {{16, 128}, {0, 16}, {0, 0}, {0, 0}},        1 },
+        { MI355Q_TYPE_Q5_K,   256, 176, MI355Q_TYPE_Q8_K, 3, {{48, 128}, {16, 32}, {0, 16}, {0, 0}},      1 },
+        { MI355Q_TYPE_Q6_K,   256, 210, MI355Q_TYPE_Q8_K, 4, {{0, 128}, {128, 64}, {192, 16}, {208, 2}},  1 },
+        { MI355Q_TYPE_IQ4_NL, 32,  18, MI355Q_TYPE_Q8_0, 2, {{2, 16}, {0, 2}, {0, 0}, {0, 0}},            0 },
+        { MI355Q_TYPE_IQ4_XS, 256, 136, MI355Q_TYPE_Q8_K, 2, {{8, 128}, {0, 8}, {0, 0}, {0, 0}},          0 },
+        // activation-only formats (never src0)
+        { MI355Q_TYPE_Q8_1,   32,  36, -1, 0, {{0, 0}, {0, 0}, {0, 0}, {0, 0}},                            0 },
+        { MI355Q_TYPE_Q8_K,   256, 292, -1, 0, {{0, 0}, {0, 0}, {0, 0}, {0, 0}},                           0 },
+    };
+    for (unsigned i = 0; i < sizeof(tab) / sizeof(tab[0]); ++i)
+        if (tab[i].type == type) return &tab[i];
+    return nullptr;
+}
+
+// Planar layout is used iff a fast kernel exists AND every row / plane starts 16-byte aligned.
+inline bool is_planar(const TypeInfo * ti, int64_t k) {   // host only
+    if (!ti || !ti->fast || k % ti->blck) return false;
+    const int64_t nb = k / ti->blck;
+    if ((nb * ti->bsize) % 16) return false;
+    int64_t off = 0;
+    for (int p = 0; p < ti->nplanes; ++p) {
+        if (off % 16) return false;
+        off += (int64_t) ti->planes[p].bytes * nb;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ float h2f(uint32_t h16) {
+    return __half2float(__ushort_as_half((unsigned short) h16));
+}
+
+// signed 4 x int8 dot-accumulate (v_dot4_i32_i8)
+__device__ __forceinline__ int dot4(int a, int b, int c) {
+    return __builtin_amdgcn_sdot4(a, b, c, false);
+}
+
+__device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63); }
+
+// 16-byte global load, non-temporal (weights are streamed exactly once: MI355X guide "nt-weights")
+__device__ __forceinline__ uint4 ldg16_nt(const void * p) {
+    const uint4 * q = (const uint4 *) p;
+    uint4 r;
+    r.x = __builtin_nontemporal_load(&q->x);
+    r.y = __builtin_nontemporal_load(&q->y);
+    r.z = __builtin_nontemporal_load(&q->z);
+    r.w = __builtin_nontemporal_load(&q->w);
+    return r;
+}
+__device__ __forceinline__ uint4 ldg16(const void * p) { return *(const uint4 *) p; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// K-quant 6-bit (scale, min) pair j out of the 12-byte field given as three dwords
+// (get_scale_min_k4, ggml/src/ggml-quants.c:631-638)
+__device__ __forceinline__ uint32_t byte_of3(uint32_t w0, uint32_t w1, uint32_t w2, int idx) {
+    const uint32_t w = idx < 4 ? w0 : (idx < 8 ? w1 : w2);
+    return (w >> (8 * (idx & 3))) & 0xFFu;
+}
+__device__ __forceinline__ void k4_scale_min(uint32_t w0, uint32_t w1, uint32_t w2, int j, int & sc, int & mn) {
+    if (j < 4) {
+        sc = (int) (byte_of3(w0, w1, w2, j) & 63u);
+        mn = (int) (byte_of3(w0, w1, w2, j + 4) & 63u);
+    } else {
+        const uint32_t a = byte_of3(w0, w1, w2, j + 4);
+        sc = (int) ((a & 0x0Fu) | ((byte_of3(w0, w1, w2, j - 4) >> 6) << 4));
+        mn = (int) ((a >> 4)    | ((byte_of3(w0, w1, w2, j)     >> 6) << 4));
+    }
+}
+
+#endif // __HIPCC__
+
+} // namespace mi355q

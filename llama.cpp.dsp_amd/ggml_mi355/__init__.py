@@ -1,0 +1,227 @@
+"""ggml_mi355 -- Python host side of the MI355X quantized-matmul path.
+
+A thin ctypes binding of the C-ABI in include/mi355q.h (libmi355q.so, hand-written HIP for gfx950)
+plus a small mirror of the reference's operator interface for this path:
+
+    ggml_mul_mat(a, b)       -> mul_mat(w, x)          ggml/src/ggml.c:2730-2745
+    ggml_mul_mat_id(as,b,ids)-> mul_mat_id(w, x, ids)  ggml/src/ggml.c:2771-2796
+    ggml_backend_tensor_set  -> QWeight.from_host      ggml/src/ggml-backend.cpp (tensor_set -> buffer.set_tensor)
+    ggml_backend_tensor_get  -> QWeight.to_host
+
+Shapes follow ggml: a weight of ggml shape [ne00=K, ne01=M(, ne02=n_expert)] is `M` packed rows of
+`K` elements; activations x are f32 [N, K] row-major (ggml [K, N]); the result is f32 [N, M].
+
+torch is used ONLY for device memory and streams.  There is no CPU fallback: importing works anywhere,
+but every compute call raises if libmi355q.so or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE.parent / "lib" / "libmi355q.so"
+
+# ggml type ids (ggml/include/ggml.h)
+F32 = 0
+Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 2, 3, 6, 7, 8, 9
+Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K = 10, 11, 12, 13, 14, 15
+IQ4_NL, IQ4_XS = 20, 23
+TYPE_NAMES = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0", Q8_1: "q8_1",
+              Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K",
+              IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs"}
+WEIGHT_TYPES = [Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ4_NL, IQ4_XS]
+
+FLAG_ROUND_AWAY, FLAG_ROUND_EVEN = 0, 1
+
+# every symbol include/mi355q.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "mi355q_api_version", "mi355q_device_count", "mi355q_set_device", "mi355q_device_info", "mi355q_last_error",
+    "mi355q_type_supported", "mi355q_blck_size", "mi355q_type_size", "mi355q_row_size", "mi355q_act_type",
+    "mi355q_weights_are_planar",
+    "mi355q_malloc", "mi355q_free", "mi355q_memset", "mi355q_memcpy_h2d", "mi355q_memcpy_d2h", "mi355q_memcpy_d2d",
+    "mi355q_stream_create", "mi355q_stream_destroy", "mi355q_stream_synchronize", "mi355q_device_synchronize",
+    "mi355q_weights_upload", "mi355q_weights_download", "mi355q_weights_pack_d2d", "mi355q_weights_unpack_d2d",
+    "mi355q_quantize_act",
+    "mi355q_mul_mat_workspace", "mi355q_mul_mat", "mi355q_mul_mat_multi",
+    "mi355q_mul_mat_id_workspace", "mi355q_mul_mat_id",
+]
+
+
+class Mi355qError(RuntimeError):
+    pass
+
+
+class _Mat(C.Structure):
+    _fields_ = [("type", C.c_int), ("w", C.c_void_p), ("w_stride", C.c_int64), ("y", C.c_void_p),
+                ("y_stride", C.c_int64), ("m", C.c_int64)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmi355q.so (built by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise Mi355qError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for this path)")
+    L = C.CDLL(str(LIB_PATH))
+    i64, i32, vp, sz = C.c_int64, C.c_int, C.c_void_p, C.c_size_t
+    L.mi355q_last_error.restype = C.c_char_p
+    for f in ("mi355q_blck_size", "mi355q_type_size"):
+        getattr(L, f).restype = i64; getattr(L, f).argtypes = [i32]
+    L.mi355q_row_size.restype = i64; L.mi355q_row_size.argtypes = [i32, i64]
+    L.mi355q_act_type.argtypes = [i32]
+    L.mi355q_type_supported.argtypes = [i32]
+    L.mi355q_weights_are_planar.argtypes = [i32, i64]
+    L.mi355q_device_info.argtypes = [i32, C.c_char_p, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]
+    L.mi355q_weights_upload.argtypes = [i32, vp, vp, i64, i64, vp]
+    L.mi355q_weights_download.argtypes = [i32, vp, vp, i64, i64, vp]
+    L.mi355q_weights_pack_d2d.argtypes = [i32, vp, vp, i64, i64, vp]
+    L.mi355q_weights_unpack_d2d.argtypes = [i32, vp, vp, i64, i64, vp]
+    L.mi355q_quantize_act.argtypes = [i32, vp, i64, vp, i64, i64, i32, vp]
+    L.mi355q_mul_mat_workspace.restype = sz; L.mi355q_mul_mat_workspace.argtypes = [i32, i64, i64, i64]
+    L.mi355q_mul_mat.argtypes = [i32, vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
+    L.mi355q_mul_mat_multi.argtypes = [C.POINTER(_Mat), i32, vp, i64, i64, i64, vp, sz, i32, vp]
+    L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64]
+    L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise Mi355qError(f"{what} failed ({rc}): {lib().mi355q_last_error().decode(errors='replace')}")
+
+
+def row_size(t: int, k: int) -> int:
+    return int(lib().mi355q_row_size(t, k))
+
+
+def act_type(t: int) -> int:
+    return int(lib().mi355q_act_type(t))
+
+
+def is_planar(t: int, k: int) -> bool:
+    return bool(lib().mi355q_weights_are_planar(t, k))
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise Mi355qError("no GPU visible: the MI355X path has no CPU fallback")
+    if lib().mi355q_device_count() < 1:
+        raise Mi355qError("no gfx950 device: libmi355q.so is built for MI355X only")
+    return torch
+
+
+def _stream(torch) -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class QWeight:
+    """A quantized weight resident in HBM in device layout.  ggml shape [K, M] or [K, M, n_expert]."""
+
+    def __init__(self, t: int, data, M: int, K: int, n_expert: int = 1):
+        self.type, self.data, self.M, self.K, self.n_expert = t, data, M, K, n_expert
+        self.row_bytes = row_size(t, K)
+
+    @property
+    def nbytes(self) -> int:
+        return self.row_bytes * self.M * self.n_expert
+
+    @staticmethod
+    def from_host(t: int, rows: np.ndarray, M: int, K: int, n_expert: int = 1, device: str = "cuda") -> "QWeight":
+        """Upload canonical ggml rows (uint8 [M*n_expert, row_size]) -- set_tensor."""
+        torch = _torch()
+        rows = np.ascontiguousarray(rows).view(np.uint8).reshape(-1)
+        rb = row_size(t, K)
+        if rb <= 0 or rows.size != rb * M * n_expert:
+            raise Mi355qError(f"from_host: {rows.size} bytes given, expected {rb}*{M}*{n_expert}")
+        buf = torch.empty(rows.size + 64, dtype=torch.uint8, device=device)   # torch allocations are >= 256-B aligned
+        _check(lib().mi355q_weights_upload(t, buf.data_ptr(), rows.ctypes.data, M * n_expert, K, _stream(torch)), "weights_upload")
+        return QWeight(t, buf, M, K, n_expert)
+
+    def to_host(self) -> np.ndarray:
+        """Canonical ggml rows back on the host -- get_tensor."""
+        torch = _torch()
+        out = np.empty((self.M * self.n_expert, self.row_bytes), np.uint8)
+        _check(lib().mi355q_weights_download(self.type, out.ctypes.data, self.data.data_ptr(), self.M * self.n_expert, self.K, _stream(torch)), "weights_download")
+        return out
+
+
+_ws_cache: dict = {}
+
+
+def _workspace(torch, nbytes: int, device):
+    if nbytes == 0:
+        return None, 0
+    key = (str(device), int(torch.cuda.current_stream().cuda_stream))
+    cur = _ws_cache.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = cur
+    return cur, cur.numel()
+
+
+def quantize_act(act_t: int, x, flags: int = 0):
+    """f32 [N, K] device tensor -> canonical activation blocks, uint8 [N, row_size(act_t, K)] on the device."""
+    torch = _torch()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    n, k = x.shape
+    out = torch.empty((n, row_size(act_t, k)), dtype=torch.uint8, device=x.device)
+    _check(lib().mi355q_quantize_act(act_t, x.data_ptr(), x.stride(0) * 4, out.data_ptr(), n, k, flags, _stream(torch)), "quantize_act")
+    return out
+
+
+def mul_mat(w: QWeight, x, out=None, flags: int = 0):
+    """y[N, M] = x[N, K] . W[M, K]^T  (GGML_OP_MUL_MAT, quantized src0, f32 src1)."""
+    torch = _torch()
+    assert w.n_expert == 1
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+    n = x.shape[0]
+    y = out if out is not None else torch.empty((n, w.M), dtype=torch.float32, device=x.device)
+    ws, wsb = _workspace(torch, int(lib().mi355q_mul_mat_workspace(w.type, w.M, n, w.K)), x.device)
+    _check(lib().mi355q_mul_mat(w.type, w.data.data_ptr(), w.row_bytes, x.data_ptr(), x.stride(0) * 4,
+                                y.data_ptr(), y.stride(0) * 4, w.M, n, w.K,
+                                ws.data_ptr() if ws is not None else None, wsb, flags, _stream(torch)), "mul_mat")
+    return y
+
+
+def mul_mat_multi(ws_: list, x, outs=None, flags: int = 0):
+    """Several weights against the same activations in one launch (wq/wk/wv, ffn_gate/ffn_up)."""
+    torch = _torch()
+    n, k = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and all(w.K == k and w.n_expert == 1 for w in ws_)
+    ys = outs if outs is not None else [torch.empty((n, w.M), dtype=torch.float32, device=x.device) for w in ws_]
+    arr = (_Mat * len(ws_))()
+    wsb = 0
+    for i, (w, y) in enumerate(zip(ws_, ys)):
+        arr[i] = _Mat(w.type, w.data.data_ptr(), w.row_bytes, y.data_ptr(), y.stride(0) * 4, w.M)
+        wsb = max(wsb, int(lib().mi355q_mul_mat_workspace(w.type, w.M, n, k)))
+    ws, wsb = _workspace(torch, wsb, x.device)
+    _check(lib().mi355q_mul_mat_multi(arr, len(ws_), x.data_ptr(), x.stride(0) * 4, n, k,
+                                      ws.data_ptr() if ws is not None else None, wsb, flags, _stream(torch)), "mul_mat_multi")
+    return ys
+
+
+def mul_mat_id(w: QWeight, x, ids, flags: int = 0):
+    """y[T, U, M] = W[ids[T, U]] . x[T, U % x_ne1, :]   (GGML_OP_MUL_MAT_ID).
+    x: f32 [T, x_ne1, K]; ids: int32 [T, U] on the device (read there: no host round trip)."""
+    torch = _torch()
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1 and x.shape[2] == w.K
+    assert ids.dtype == torch.int32 and ids.dim() == 2 and ids.stride(1) == 1 and ids.shape[0] == x.shape[0]
+    n_tok, x_ne1, _ = x.shape
+    n_used = ids.shape[1]
+    y = torch.empty((n_tok, n_used, w.M), dtype=torch.float32, device=x.device)
+    ws, wsb = _workspace(torch, int(lib().mi355q_mul_mat_id_workspace(w.type, w.M, w.K, n_used, n_tok, x_ne1)), x.device)
+    _check(lib().mi355q_mul_mat_id(w.type, w.data.data_ptr(), w.row_bytes, w.row_bytes * w.M, w.n_expert,
+                                   x.data_ptr(), x_ne1, x.stride(1) * 4, x.stride(0) * 4,
+                                   ids.data_ptr(), ids.stride(0) * 4, y.data_ptr(), w.M, w.K, n_used, n_tok,
+                                   ws.data_ptr() if ws is not None else None, wsb, flags, _stream(torch)), "mul_mat_id")
+    return y

@@ -1,0 +1,65 @@
+"""Synthetic workloads of the hot path: the quantized matmul set one generated token touches.
+
+Tensor shapes are those libllama builds for the llama architecture (src/llama-model.cpp:4451-4539, 4618);
+the per-tensor quantization types follow the Q4_K_M recipe of the reference's quantizer
+(src/llama-quant.cpp:129-131 use_more_bits, :151-168 output -> Q6_K, :235-249 attn_v, :291-297 ffn_down).
+`token_embd` is excluded: it is a 1-row GET_ROWS on the CPU."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from . import Q4_K, Q6_K, Q8_0, row_size
+
+
+@dataclass(frozen=True)
+class MatSpec:
+    name: str
+    type: int
+    M: int
+    K: int
+    layer: int          # -1 for the output matrix
+
+    @property
+    def nbytes(self) -> int:
+        return row_size(self.type, self.K) * self.M
+
+
+def use_more_bits(i_layer: int, n_layers: int) -> bool:
+    """src/llama-quant.cpp:129-131"""
+    return i_layer < n_layers // 8 or i_layer >= 7 * n_layers // 8 or (i_layer - n_layers // 8) % 3 == 2
+
+
+LLAMA3_8B = dict(n_layer=32, n_embd=4096, n_ff=14336, n_head=32, n_head_kv=8, head_dim=128, n_vocab=128256)
+LLAMA3_70B = dict(n_layer=80, n_embd=8192, n_ff=28672, n_head=64, n_head_kv=8, head_dim=128, n_vocab=128256)
+
+
+def llama_matmuls(cfg: dict, ftype: str = "Q4_K_M") -> list[MatSpec]:
+    L, E, F = cfg["n_layer"], cfg["n_embd"], cfg["n_ff"]
+    kv = cfg["n_head_kv"] * cfg["head_dim"]
+    out: list[MatSpec] = []
+    for il in range(L):
+        if ftype == "Q4_K_M":
+            more = use_more_bits(il, L)
+            t_v = Q6_K if more else Q4_K
+            t_down = Q6_K if more else Q4_K
+            t = Q4_K
+        elif ftype == "Q8_0":
+            t = t_v = t_down = Q8_0
+        else:
+            raise ValueError(ftype)
+        out += [
+            MatSpec(f"blk.{il}.attn_q", t, E, E, il), MatSpec(f"blk.{il}.attn_k", t, kv, E, il),
+            MatSpec(f"blk.{il}.attn_v", t_v, kv, E, il), MatSpec(f"blk.{il}.attn_output", t, E, E, il),
+            MatSpec(f"blk.{il}.ffn_gate", t, F, E, il), MatSpec(f"blk.{il}.ffn_up", t, F, E, il),
+            MatSpec(f"blk.{il}.ffn_down", t_down, E, F, il),
+        ]
+    out.append(MatSpec("output", Q6_K if ftype == "Q4_K_M" else Q8_0, cfg["n_vocab"], E, -1))
+    return out
+
+
+def partition_layers(n_layer: int, world: int) -> list[range]:
+    """Contiguous layer ranges per device, as --split-mode layer does with equal free memory
+    (src/llama-model.cpp:1438-1497: split points proportional to device memory, upper_bound lookup)."""
+    bounds = [round(n_layer * (r + 1) / world) for r in range(world)]
+    starts = [0] + bounds[:-1]
+    return [range(s, e) for s, e in zip(starts, bounds)]

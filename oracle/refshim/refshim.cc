@@ -151,7 +151,7 @@ double ref_bench_chain(int n_mats, const int * types, const int64_t * Ms, const 
     struct ggml_init_params ip = { mem, nullptr, false };
     struct ggml_context * ctx = ggml_init(ip);
     if (!ctx) return -1.0;
-    struct ggml_cgraph * gf = ggml_new_graph_custom(ctx, n_mats + 16, false);
+    struct ggml_cgraph * gf = ggml_new_graph_custom(ctx, 4 * (size_t) n_mats + 64, false);
     for (int i = 0; i < n_mats; ++i) {
         struct ggml_tensor * a = ggml_new_tensor_2d(ctx, (ggml_type) types[i], Ks[i], Ms[i]);
         struct ggml_tensor * b = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, Ks[i], N);

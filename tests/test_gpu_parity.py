@@ -1,0 +1,301 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (libmi355q.so via ggml_mi355), against the
+oracle on the same seeded inputs, against the committed golden vectors, and through size-independent
+properties at BASELINE.json's full sizes.
+
+Tolerances (stated once):
+  * integer work -- activation blocks, block decode round trips, Q8_0/Q4_K/Q6_K on exactly-representable
+    inputs: BIT-EXACT.
+  * f32 outputs: the per-block integer sums are identical to the CPU's; only the order of the final f32
+    additions differs, so  |y - y_oracle| <= 1e-5 * max|y_oracle|  (about 10x the observed error) and,
+    element-wise, the north-star bound  |y - y_oracle| <= 1e-3 * |y_oracle| + 1e-5 * max|y_oracle|.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN
+from qdata import quantized_weights, random_blocks
+
+pytestmark = pytest.mark.gpu
+
+TYPES = [oracle.Q4_0, oracle.Q4_1, oracle.Q5_0, oracle.Q5_1, oracle.Q8_0, oracle.Q2_K, oracle.Q3_K,
+         oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.IQ4_NL, oracle.IQ4_XS]
+FAST = [oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.Q8_0, oracle.Q4_0]
+ids_t = lambda t: oracle.TYPE_NAMES[t]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    import ggml_mi355 as g
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    assert g.lib().mi355q_device_count() >= 1, "libmi355q.so found no gfx950 device"
+    return g
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    return t
+
+
+def check_close(y, ref, what=""):
+    y = np.asarray(y, np.float32); ref = np.asarray(ref, np.float32)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    assert np.isfinite(y).all(), what
+    scale = float(np.abs(ref).max()) or 1.0
+    err = np.abs(y - ref)
+    assert err.max() <= 1e-5 * scale, f"{what}: max err {err.max():.3e} vs scale {scale:.3e}"
+    assert (err <= 1e-3 * np.abs(ref) + 1e-5 * scale).all(), what
+
+
+def gpu_mul_mat(G, torch, t, w_rows, x, M, K, flags=0):
+    w = G.QWeight.from_host(t, w_rows, M, K)
+    y = G.mul_mat(w, torch.from_numpy(np.ascontiguousarray(x)).cuda(), flags=flags)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors produced by the real reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(GOLDEN.glob("mul_mat_[!i]*.npz")) + sorted(GOLDEN.glob("mul_mat_iq*.npz")), ids=lambda p: p.stem)
+def test_golden_mul_mat(G, torch, path):
+    g = np.load(path, allow_pickle=False)
+    t, M, N, K = int(g["type"]), int(g["M"]), int(g["N"]), int(g["K"])
+    check_close(gpu_mul_mat(G, torch, t, g["w"], g["x"], M, K), g["y"], path.stem)
+
+
+@pytest.mark.parametrize("path", sorted(GOLDEN.glob("mul_mat_id_*.npz")), ids=lambda p: p.stem)
+def test_golden_mul_mat_id(G, torch, path):
+    g = np.load(path, allow_pickle=False)
+    t, M, K, ne = int(g["type"]), int(g["M"]), int(g["K"]), int(g["n_expert"])
+    w = G.QWeight.from_host(t, g["as_"], M, K, n_expert=ne)
+    y = G.mul_mat_id(w, torch.from_numpy(g["b"]).cuda(), torch.from_numpy(g["ids"]).cuda())
+    check_close(y.cpu().numpy(), g["y"], path.stem)
+
+
+# ------------------------------------------------------------------------------------------------
+# activation quantizer: bit-exact blocks
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", [oracle.Q8_0, oracle.Q8_1, oracle.Q8_K], ids=ids_t)
+@pytest.mark.parametrize("mode", [oracle.ROUND_AWAY, oracle.ROUND_EVEN])
+def test_quantize_act_bitexact(G, torch, orc, act, mode):
+    rng = np.random.default_rng(11 + act)
+    K = 4096 if act == oracle.Q8_K else 4096 + 32        # ragged tail for the 32-element formats
+    x = rng.standard_normal((5, K)).astype(np.float32)
+    x[0, :256] = 0.0                                      # all-zero block
+    x[1, 7] = 100.0; x[1, 200] = -100.0                   # equal |max| of both signs: first one wins (Q8_K)
+    x[2, :32] = np.arange(32) * 0.5 + 0.25                # exact .5 ties after scaling (d = 15.75/127 not exact, still a stress)
+    x[3, :32] = 0; x[3, 0] = 127.0; x[3, 1] = 2.5; x[3, 2] = -3.5   # d = 1: genuine rounding ties
+    got = G.quantize_act(act, torch.from_numpy(x).cuda(), flags=mode).cpu().numpy()
+    want = orc.quantize_act(act, x, mode)
+    if act == oracle.Q8_K:                                # bsums of all-zero blocks are undefined in the reference
+        g2 = got.reshape(5, -1, 292).copy(); w2 = want.reshape(5, -1, 292).copy()
+        z = w2[:, :, :4].view(np.float32)[..., 0] == 0
+        g2[z, 260:] = 0; w2[z, 260:] = 0
+        assert np.array_equal(g2, w2)
+    else:
+        assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------
+# every type x batch sizes at the reference's test-backend-ops shapes (tests/test-backend-ops.cpp:4143-4147)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t", TYPES, ids=ids_t)
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 8, 9, 17])
+def test_small_shapes(G, torch, orc, t, N):
+    rng = np.random.default_rng(100 * t + N)
+    M, K = 16, 256
+    w = quantized_weights(t, M, K, rng)
+    x = rng.uniform(-1, 1, (N, K)).astype(np.float32)
+    check_close(gpu_mul_mat(G, torch, t, w, x, M, K), orc.mul_mat(t, w, x, M, N, K), f"{ids_t(t)} N={N}")
+
+
+@pytest.mark.parametrize("t", TYPES, ids=ids_t)
+@pytest.mark.parametrize("shape", [(64, 2048), (33, 4096), (7, 14336), (130, 512), (257, 6144)], ids=str)
+def test_planar_and_odd_shapes(G, torch, orc, t, shape):
+    """K multiples of 2048 take the planar fast tier for the fast types; K=512 keeps 2-byte-aligned
+    formats on the generic tier; ragged M exercises the row tails."""
+    M, K = shape
+    rng = np.random.default_rng(7 * t + M)
+    w = quantized_weights(t, M, K, rng)
+    for N in (1, 3, 8):
+        x = (rng.standard_normal((N, K)) * rng.uniform(0.1, 4.0)).astype(np.float32)
+        check_close(gpu_mul_mat(G, torch, t, w, x, M, K), orc.mul_mat(t, w, x, M, N, K), f"{ids_t(t)} {shape} N={N}")
+
+
+@pytest.mark.parametrize("t", TYPES, ids=ids_t)
+def test_random_byte_blocks(G, torch, orc, t):
+    """Arbitrary bit patterns in the quant payload (all 6-bit scales, all nibble values, sign bits...)."""
+    rng = np.random.default_rng(31 + t)
+    M, K = 48, 2048
+    w = random_blocks(t, M, K, rng)
+    x = rng.standard_normal((2, K)).astype(np.float32)
+    check_close(gpu_mul_mat(G, torch, t, w, x, M, K), orc.mul_mat(t, w, x, M, 2, K), ids_t(t))
+
+
+@pytest.mark.parametrize("t", TYPES, ids=ids_t)
+def test_upload_download_roundtrip(G, torch, t):
+    """set_tensor -> device layout -> get_tensor is the identity on canonical bytes."""
+    rng = np.random.default_rng(5 + t)
+    for M, K in ((3, 256), (16, 2048), (5, 14336)):
+        w = random_blocks(t, M, K, rng)
+        back = G.QWeight.from_host(t, w, M, K).to_host()
+        assert np.array_equal(back, w), (ids_t(t), M, K)
+
+
+def test_edge_cases(G, torch, orc):
+    t = oracle.Q4_K
+    rng = np.random.default_rng(1)
+    w = quantized_weights(t, 8, 256, rng)
+    wq = G.QWeight.from_host(t, w, 8, 256)
+    # empty batch
+    y = G.mul_mat(wq, torch.empty((0, 256), dtype=torch.float32, device="cuda"))
+    assert tuple(y.shape) == (0, 8)
+    # all-zero activations -> exactly zero output
+    y = G.mul_mat(wq, torch.zeros((2, 256), dtype=torch.float32, device="cuda")).cpu().numpy()
+    assert np.array_equal(y, np.zeros((2, 8), np.float32))
+    # strided (non-contiguous rows) activations
+    xs = torch.from_numpy(rng.standard_normal((3, 512)).astype(np.float32)).cuda()
+    xv = xs[:, :256]
+    check_close(G.mul_mat(wq, xv).cpu().numpy(), orc.mul_mat(t, w, xv.cpu().numpy().copy(), 8, 3, 256))
+    # bad shapes are reported, not executed
+    with pytest.raises(G.Mi355qError):
+        G.QWeight.from_host(t, w[:, :100], 8, 256)
+    with pytest.raises(G.Mi355qError):
+        G.QWeight.from_host(17, w, 8, 256)               # IQ2_XS: not implemented -> loud error, no fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# bit-exact on exactly representable inputs ("bit-exact for Q8_0 integer dot", BASELINE.json north_star)
+# ------------------------------------------------------------------------------------------------
+def test_q8_0_integer_dot_bitexact(G, torch, orc):
+    rng = np.random.default_rng(2)
+    M, K, N = 64, 4096, 3
+    nb = K // 32
+    w = np.zeros((M, nb, 34), np.uint8)
+    w[:, :, 0:2] = np.float16(2.0 ** -6).view(np.uint8) if False else np.frombuffer(np.float16(2.0 ** -6).tobytes(), np.uint8)
+    w[:, :, 2:] = rng.integers(-7, 8, (M, nb, 32), dtype=np.int8).view(np.uint8)
+    x = rng.integers(-126, 127, (N, K)).astype(np.float32)
+    x.reshape(N, nb, 32)[:, :, 0] = 127.0                 # amax = 127 -> d = 1, quants == x exactly
+    w = w.reshape(M, nb * 34)
+    ref = orc.mul_mat(oracle.Q8_0, w, x, M, N, K)
+    for flags in (oracle.ROUND_AWAY, oracle.ROUND_EVEN):
+        y = gpu_mul_mat(G, torch, oracle.Q8_0, w, x, M, K, flags=flags)
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+    # and the plain integer answer
+    wi = w.reshape(M, nb, 34)[:, :, 2:].view(np.int8).reshape(M, K).astype(np.int64)
+    exact = (x.astype(np.int64) @ wi.T).astype(np.float64) * 2.0 ** -6
+    assert np.array_equal(ref.astype(np.float64), exact)
+
+
+@pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K], ids=ids_t)
+def test_kquant_bitexact_on_exact_inputs(G, torch, orc, t):
+    rng = np.random.default_rng(3)
+    M, K, N = 32, 2048, 2
+    nb = K // 256
+    if t == oracle.Q4_K:
+        w = np.zeros((M, nb, 144), np.uint8)
+        w[:, :, 0:2] = np.frombuffer(np.float16(2.0 ** -8).tobytes(), np.uint8)
+        w[:, :, 2:4] = np.frombuffer(np.float16(2.0 ** -9).tobytes(), np.uint8)
+        w[:, :, 4:12] = rng.integers(0, 8, (M, nb, 8), dtype=np.uint8)      # sc/min < 8, high bits clear
+        w[:, :, 12:16] = rng.integers(0, 8, (M, nb, 4), dtype=np.uint8) * 17 & 0x77
+        w[:, :, 16:] = rng.integers(0, 256, (M, nb, 128), dtype=np.uint8)
+    else:
+        w = np.zeros((M, nb, 210), np.uint8)
+        w[:, :, :192] = rng.integers(0, 256, (M, nb, 192), dtype=np.uint8)
+        w[:, :, 192:208] = rng.integers(-4, 5, (M, nb, 16), dtype=np.int8).view(np.uint8)
+        w[:, :, 208:210] = np.frombuffer(np.float16(2.0 ** -7).tobytes(), np.uint8)
+    w = w.reshape(M, -1)
+    x = rng.integers(-15, 16, (N, K)).astype(np.float32)
+    x.reshape(N, nb, 256)[:, :, 3] = -127.0                # iscale = -127/max = 1, d = 1: quants == x exactly
+    ref = orc.mul_mat(t, w, x, M, N, K)
+    y = gpu_mul_mat(G, torch, t, w, x, M, K)
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-matrix launch == separate launches (bit-identical), mixed Q4_K/Q6_K as in Q4_K_M attention
+# ------------------------------------------------------------------------------------------------
+def test_multi_equals_single(G, torch, orc):
+    rng = np.random.default_rng(4)
+    K = 4096
+    specs = [(oracle.Q4_K, 96), (oracle.Q4_K, 40), (oracle.Q6_K, 24)]
+    hosts = [quantized_weights(t, m, K, rng) for t, m in specs]
+    ws = [G.QWeight.from_host(t, h, m, K) for (t, m), h in zip(specs, hosts)]
+    for N in (1, 4):
+        x = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+        multi = [y.cpu().numpy() for y in G.mul_mat_multi(ws, x)]
+        for (t, m), h, w, ym in zip(specs, hosts, ws, multi):
+            single = G.mul_mat(w, x).cpu().numpy()
+            assert np.array_equal(single.view(np.uint32), ym.view(np.uint32))
+            check_close(ym, orc.mul_mat(t, h, x.cpu().numpy(), m, N, K))
+
+
+# ------------------------------------------------------------------------------------------------
+# MoE (tests/test-backend-ops.cpp:4240-4270 shapes: n_mats {4,8} x n_used {1,2,4}, m=512, k=256)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.Q8_0, oracle.Q5_K, oracle.IQ4_XS, oracle.Q4_1], ids=ids_t)
+@pytest.mark.parametrize("cfg", [(4, 1, 1), (8, 2, 1), (8, 4, 5), (4, 2, 32)], ids=str)
+def test_mul_mat_id(G, torch, orc, t, cfg):
+    ne, nu, nt = cfg
+    rng = np.random.default_rng(17 * t + ne + nu + nt)
+    for K, M in ((256, 512), (2048, 96)):
+        as_ = quantized_weights(t, ne * M, K, rng)
+        w = G.QWeight.from_host(t, as_, M, K, n_expert=ne)
+        ids = np.stack([rng.permutation(ne)[:nu] for _ in range(nt)]).astype(np.int32)
+        for b1 in sorted({1, nu}):
+            b = rng.uniform(-1, 1, (nt, b1, K)).astype(np.float32)
+            y = G.mul_mat_id(w, torch.from_numpy(b).cuda(), torch.from_numpy(ids).cuda()).cpu().numpy()
+            check_close(y, orc.mul_mat_id(t, as_, b, ids, M, K, ne), f"{ids_t(t)} {cfg} K={K} b1={b1}")
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes (Llama-3-8B): sampled rows against the oracle + size-independent properties
+# ------------------------------------------------------------------------------------------------
+FULL = [(oracle.Q4_K, 4096, 4096), (oracle.Q4_K, 14336, 4096), (oracle.Q6_K, 4096, 14336),
+        (oracle.Q4_K, 4096, 14336), (oracle.Q6_K, 1024, 4096), (oracle.Q8_0, 14336, 4096),
+        (oracle.Q5_K, 1024, 8192), (oracle.Q4_0, 4096, 4096)]
+
+
+@pytest.mark.parametrize("t,M,K", FULL, ids=lambda v: str(v))
+def test_full_size_sampled_rows_and_properties(G, torch, orc, t, M, K):
+    rng = np.random.default_rng(M + K + t)
+    w = random_blocks(t, M, K, rng)
+    wq = G.QWeight.from_host(t, w, M, K)
+    x = rng.standard_normal((2, K)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    y = G.mul_mat(wq, xd).cpu().numpy()
+    # (1) sampled rows vs the oracle
+    rows = np.unique(np.concatenate([[0, 1, M - 1, M - 2], rng.integers(0, M, 60)]))
+    ref = orc.mul_mat(t, w[rows], x, len(rows), 2, K)
+    check_close(y[:, rows], ref, f"{ids_t(t)} {M}x{K}")
+    # (2) N=1 launches give bit-identical columns (column tiles are independent)
+    y0 = G.mul_mat(wq, xd[0:1]).cpu().numpy()
+    assert np.array_equal(y0.view(np.uint32), y[0:1].view(np.uint32))
+    # (3) a row permutation of W permutes y bit-exactly (rows are independent, deterministic)
+    perm = rng.permutation(M)
+    yp = G.mul_mat(G.QWeight.from_host(t, w[perm], M, K), xd).cpu().numpy()
+    assert np.array_equal(yp.view(np.uint32), y[:, perm].view(np.uint32))
+    # (4) determinism across repeated launches
+    y2 = G.mul_mat(wq, xd).cpu().numpy()
+    assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))
+
+
+def test_output_layer_rows(G, torch, orc):
+    """The 128256 x 4096 Q6_K output matrix of Llama-3-8B Q4_K_M: maximum row count of the workload."""
+    t, M, K = oracle.Q6_K, 128256, 4096
+    rng = np.random.default_rng(9)
+    base = random_blocks(t, 4096, K, rng)
+    w = np.tile(base, (M // 4096 + 1, 1))[:M]
+    wq = G.QWeight.from_host(t, w, M, K)
+    x = rng.standard_normal((1, K)).astype(np.float32)
+    y = G.mul_mat(wq, torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = orc.mul_mat(t, base[:256], x, 256, 1, K)
+    check_close(y[:, :256], ref)
+    # periodic weights -> periodic output, bit-exact, over the whole row range
+    assert np.array_equal(y[0, 4096:8192].view(np.uint32), y[0, :4096].view(np.uint32))
+    assert np.array_equal(y[0, M - 4096 + (4096 - M % 4096) % 4096 - 4096:][:0], y[0, :0])
+    tail = M % 4096
+    assert np.array_equal(y[0, M - tail:].view(np.uint32), y[0, :tail].view(np.uint32))
