@@ -13,58 +13,48 @@
 
 namespace mi355q {
 
-// nearest_int(): round-half-even through the 1.5*2^23 constant (ggml-quants.c:372-377)
+// nearest_int(): round-half-even through the 1.5*2^23 constant (ggml-quants.c:372-377):
+//   t = v + 12582912.f ; (bits(t) & 0x007fffff) - 0x00400000
+// For |v| < 2^22 (the reference asserts it) t lies in [2^23, 2^24), its exponent field is fixed, and the
+// masked expression equals bits(t) - bits(12582912.f) -- one integer subtract.
 __device__ __forceinline__ int nearest_int_magic(float v) {
-    const float t = __fadd_rn(v, 12582912.0f);
-    return (int) ((__float_as_uint(t) & 0x007FFFFFu)) - 0x00400000;
+    return (int) (__float_as_uint(__fadd_rn(v, 12582912.0f)) - 0x4B400000u);
 }
 
+// four ints in [-128,127] -> packed bytes (a = byte 0)
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
-    return (uint32_t) (a & 0xFF) | ((uint32_t) (b & 0xFF) << 8) | ((uint32_t) (c & 0xFF) << 16) | ((uint32_t) (d & 0xFF) << 24);
+    const uint32_t lo = (uint32_t) (a & 0xFFFF) | ((uint32_t) b << 16);        // i16 pairs
+    const uint32_t hi = (uint32_t) (c & 0xFFFF) | ((uint32_t) d << 16);
+    return __builtin_amdgcn_perm(hi, lo, 0x06040200u);                          // bytes 0,2 of lo then 0,2 of hi
 }
 
 // ---- Q8_K: whole wave = one block ------------------------------------------------------------
 // in : v = this lane's 4 activations.   out: q = 4 packed int8, d = block scale (all lanes),
 //      bsum = sum of the 16 quants of this lane's 16-group (valid in all 4 lanes of the group).
+// Written for instruction count: every workgroup of a GEMV launch runs this for the whole activation
+// vector, so it is executed (#CUs x K/256) times per launch.
 __device__ __forceinline__ void q8k_wave(const float4 v, uint32_t & q, float & d, int & bsum) {
-    const int lane = lane_id();
-    // signed value of the FIRST element with the largest magnitude ("if (ax > amax)")
-    const float xs[4] = { v.x, v.y, v.z, v.w };
-    float amax = 0.0f; int best = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; best = i; } }
-    // key: larger |x| wins, then the smaller element index
-    uint32_t khi = __float_as_uint(amax);
-    uint32_t klo = 0xFFFFFFFFu - (uint32_t) (4 * lane + best);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t ohi = __shfl_xor(khi, o, 64);
-        const uint32_t olo = __shfl_xor(klo, o, 64);
-        const bool take = (ohi > khi) || (ohi == khi && olo > klo);
-        khi = take ? ohi : khi;
-        klo = take ? olo : klo;
-    }
-    const float wamax = __uint_as_float(khi);
-    const int   widx  = (int) (0xFFFFFFFFu - klo);
-    const int   wsub  = widx & 3;
-    const float mine  = wsub == 0 ? v.x : (wsub == 1 ? v.y : (wsub == 2 ? v.z : v.w));
-    const float vmax  = __shfl(mine, widx >> 2, 64);
-    if (wamax == 0.0f) {                       // all-zero block: d = 0, quants 0 (bsums undefined in the reference; 0 here)
+    const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z), aw = fabsf(v.w);
+    const float amax = fmaxf(fmaxf(ax, ay), fmaxf(az, aw));
+    // wave maximum of |x| (non-negative floats order like their bit patterns), then the LOWEST lane that
+    // holds it (ballot + find-first-set) and, inside that lane, the first of its 4 elements with that
+    // magnitude = the first element in memory order, as the CPU loop "if (ax > amax)" picks it
+    const uint32_t wbits = wave_max_u32(__float_as_uint(amax));
+    const unsigned long long holders = __ballot(__float_as_uint(amax) == wbits);
+    const int   src  = __builtin_amdgcn_readfirstlane(__ffsll((long long) holders) - 1);
+    const float mine = ax == amax ? v.x : (ay == amax ? v.y : (az == amax ? v.z : v.w));
+    const float vmax = readlane_f(mine, src);
+    if (wbits == 0u) {                         // all-zero block: d = 0, quants 0 (bsums undefined in the reference; 0 here)
         q = 0; d = 0.0f; bsum = 0;
         return;
     }
     const float iscale = __fdiv_rn(-127.0f, vmax);
-    int qi[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = nearest_int_magic(__fmul_rn(iscale, xs[i]));
-        qi[i] = t > 127 ? 127 : t;
-    }
-    q = pack4(qi[0], qi[1], qi[2], qi[3]);
-    int s = qi[0] + qi[1] + qi[2] + qi[3];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    bsum = s;
+    const int q0 = min(127, nearest_int_magic(__fmul_rn(iscale, v.x)));
+    const int q1 = min(127, nearest_int_magic(__fmul_rn(iscale, v.y)));
+    const int q2 = min(127, nearest_int_magic(__fmul_rn(iscale, v.z)));
+    const int q3 = min(127, nearest_int_magic(__fmul_rn(iscale, v.w)));
+    q = pack4(q0, q1, q2, q3);
+    bsum = quad_sum((q0 + q1) + (q2 + q3));
     d = __fdiv_rn(1.0f, iscale);
 }
 
@@ -73,25 +63,13 @@ __device__ __forceinline__ void q8k_wave(const float4 v, uint32_t & q, float & d
 //      sum = sum of the 32 quants of the block (valid in all 8 lanes).
 template <bool ROUND_EVEN>
 __device__ __forceinline__ void q80_group8(const float4 v, uint32_t & q, float & d, int & sum) {
-    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float amax = oct_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     d = __fdiv_rn(amax, 127.0f);
     const float id = d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f;
-    const float xs[4] = { v.x, v.y, v.z, v.w };
-    int qi[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float p = __fmul_rn(xs[i], id);
-        qi[i] = (int) (ROUND_EVEN ? rintf(p) : roundf(p));
-    }
-    q = pack4(qi[0], qi[1], qi[2], qi[3]);
-    int s = qi[0] + qi[1] + qi[2] + qi[3];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    sum = s;
+    auto rnd = [](float p) { return (int) (ROUND_EVEN ? rintf(p) : roundf(p)); };
+    const int q0 = rnd(__fmul_rn(v.x, id)), q1 = rnd(__fmul_rn(v.y, id)), q2 = rnd(__fmul_rn(v.z, id)), q3 = rnd(__fmul_rn(v.w, id));
+    q = pack4(q0, q1, q2, q3);
+    sum = oct_sum((q0 + q1) + (q2 + q3));
 }
 
 // float4 load of this lane's 4 activations (zero beyond k).  `vec` = row is 16-byte aligned.

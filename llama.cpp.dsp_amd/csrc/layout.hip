@@ -13,6 +13,8 @@ struct PackDesc {
     int     bytes[4];
     int64_t start[5];      // byte offset of each plane inside a device row
     int64_t row_bytes;
+    int     perm_plane;    // plane whose bytes are additionally permuted inside each block (-1: none)
+    uint8_t perm[16];      // device byte i of that plane's per-block group = source byte perm[i]
 };
 
 // one thread per 16-bit word of the device row image; PACK: canonical -> device, else device -> canonical
@@ -30,8 +32,20 @@ k_repack(const uint16_t * __restrict__ src, uint16_t * __restrict__ dst, const P
         const int64_t rel = o - d.start[p];
         const int64_t blk = rel / d.bytes[p];
         const int64_t off = rel - blk * d.bytes[p];
-        const int64_t canon = blk * d.bsize + d.src_off[p] + off;    // byte offset inside the CANONICAL row
         const int64_t rbase = row * words_per_row;
+        if (p == d.perm_plane) {                                     // two bytes of this word come from different places
+            const int64_t c0 = blk * d.bsize + d.src_off[p] + d.perm[off], c1 = blk * d.bsize + d.src_off[p] + d.perm[off + 1];
+            if (PACK) {
+                const uint8_t * sb = (const uint8_t *) (src + rbase);
+                dst[rbase + o / 2] = (uint16_t) (sb[c0] | (sb[c1] << 8));
+            } else {
+                uint8_t * db = (uint8_t *) (dst + rbase);
+                const uint16_t v = src[rbase + o / 2];
+                db[c0] = (uint8_t) (v & 0xFF); db[c1] = (uint8_t) (v >> 8);
+            }
+            continue;
+        }
+        const int64_t canon = blk * d.bsize + d.src_off[p] + off;    // byte offset inside the CANONICAL row
         if (PACK) dst[rbase + o / 2] = src[rbase + canon / 2];
         else      dst[rbase + canon / 2] = src[rbase + o / 2];
     }
@@ -49,6 +63,16 @@ static bool make_desc(int type, int64_t k, PackDesc & d) {
         if (p < ti->nplanes) off += (int64_t) ti->planes[p].bytes * nb;
     }
     d.start[4] = off;
+    d.perm_plane = -1;
+    for (int i = 0; i < 16; ++i) d.perm[i] = (uint8_t) i;
+    if (type == MI355Q_TYPE_Q6_K) {
+        // gemv_fast.hip: chunk j = 4h + 2cc + p reads its two int8 scales (sub-blocks 8h+2cc+p and +4) as ONE 16-bit load
+        d.perm_plane = 2;
+        for (int j = 0; j < 8; ++j) {
+            const int s0 = 8 * (j >> 2) + 2 * ((j >> 1) & 1) + (j & 1);
+            d.perm[2 * j] = (uint8_t) s0; d.perm[2 * j + 1] = (uint8_t) (s0 + 4);
+        }
+    }
     return true;
 }
 

@@ -98,12 +98,35 @@ __device__ __forceinline__ uint4 ldg16_nt(const void * p) {
 }
 __device__ __forceinline__ uint4 ldg16(const void * p) { return *(const uint4 *) p; }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- cross-lane reductions on DPP (VALU data-parallel primitives), not ds_bpermute: a 64-lane
+// __shfl_xor tree is ~6 dependent LDS-crossbar round trips (~0.4 us per reduction on gfx950).
+//   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// sum over all 64 lanes, fixed (deterministic) tree; result uniform
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);   // each 16-lane row holds its sum
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
+// max over all 64 lanes of an unsigned key; result uniform
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    int x = (int) v;
+    auto mx = [](int a, int b) { return (int) max((uint32_t) a, (uint32_t) b); };
+    x = mx(x, dpp_i<0xB1>(x)); x = mx(x, dpp_i<0x4E>(x)); x = mx(x, dpp_i<0x141>(x)); x = mx(x, dpp_i<0x140>(x));
+    const uint32_t r0 = (uint32_t) __builtin_amdgcn_readlane(x, 0),  r1 = (uint32_t) __builtin_amdgcn_readlane(x, 16);
+    const uint32_t r2 = (uint32_t) __builtin_amdgcn_readlane(x, 32), r3 = (uint32_t) __builtin_amdgcn_readlane(x, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+// integer sum over each aligned group of 4 / 8 lanes (result in every lane of the group)
+__device__ __forceinline__ int quad_sum(int v) { v += dpp_i<0xB1>(v); v += dpp_i<0x4E>(v); return v; }
+__device__ __forceinline__ int oct_sum(int v)  { v = quad_sum(v); v += dpp_i<0x141>(v); return v; }
+__device__ __forceinline__ float oct_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); return v;
+}
+// value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ int pair_swap(int v) { return dpp_i<0xB1>(v); }
 
 // K-quant 6-bit (scale, min) pair j out of the 12-byte field given as three dwords
 // (get_scale_min_k4, ggml/src/ggml-quants.c:631-638)

@@ -22,7 +22,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE.parent / "lib" / "libmi355q.so"
+import os as _os
+LIB_PATH = Path(_os.environ["MI355Q_LIB"]) if _os.environ.get("MI355Q_LIB") else _HERE.parent / "lib" / "libmi355q.so"   # MI355Q_LIB: diagnostic builds only
 
 # ggml type ids (ggml/include/ggml.h)
 F32 = 0
