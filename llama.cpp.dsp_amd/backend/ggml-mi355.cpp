@@ -1,0 +1,462 @@
+// ggml-mi355.cpp -- ggml backend plugin "MI355" (libggml-mi355.so).
+//
+// A dynamically loadable ggml backend (GGML_BACKEND_DL: exports ggml_backend_init / ggml_backend_score,
+// ggml/src/ggml-backend-impl.h:215-251) that the reference's unmodified llama-bench / test-backend-ops
+// pick up through GGML_BACKEND_PATH (ggml/src/ggml-backend-reg.cpp:585-589).  It implements the four
+// vtables of ggml-backend-impl.h (reg :191-207, device :137-185, buffer type :17-35, buffer :41-66,
+// backend :87-124) in plain C++ over the C-ABI of libmi355q.so (include/mi355q.h): no HIP code here.
+//
+// Scope: the quantized MUL_MAT / MUL_MAT_ID hot path.  supports_op is true for
+//   * GGML_OP_MUL_MAT    with quantized src0 (the 12 types of mi355q_type_supported), f32 src1, f32 dst
+//   * GGML_OP_MUL_MAT_ID with the same src0 types
+//   * the no-op view ops NONE / RESHAPE / VIEW / PERMUTE / TRANSPOSE on our own buffers
+// everything else stays on the CPU backend.  The fork's own DSP backend (ggml/src/ggml-dsp/ggml-dsp.cpp)
+// is the structural template for where each hook goes; none of its code is reused.
+//
+// Device layout of quantized tensors: set_tensor converts canonical ggml rows into the planar device rows
+// of libmi355q (same row size and stride; only the byte order inside a row changes), get_tensor converts
+// back, so buffer contents stay opaque-but-round-trippable as the buffer interface requires.
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "ggml-backend-impl.h"
+#include "ggml-impl.h"
+
+#include "mi355q.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define MI355_MAX_DEVICES 16
+
+#define MQ_CHECK(expr)                                                                                             \
+    do {                                                                                                           \
+        const int rc_ = (expr);                                                                                    \
+        if (rc_ != MI355Q_OK) GGML_ABORT("MI355: %s failed (%d): %s", #expr, rc_, mi355q_last_error());            \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ contexts
+struct mi355_device_ctx {
+    int         index;
+    std::string name;          // "MI355_0"
+    std::string description;
+    struct ggml_backend_buffer_type buft;
+    std::string buft_name;
+};
+
+struct mi355_buffer_ctx {
+    int    device;
+    void * base;
+};
+
+struct mi355_backend_ctx {
+    int         device;
+    std::string name;
+    void *      stream    = nullptr;
+    void *      workspace = nullptr;
+    size_t      workspace_size = 0;
+};
+
+static ggml_guid_t mi355_guid() {
+    static ggml_guid guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x71, 0x6d, 0x61, 0x74, 0x6d, 0x75, 0x6c, 0x2d, 0x31 };
+    return &guid;
+}
+
+static bool mi355_is_quant(enum ggml_type t) { return mi355q_type_supported((int) t) == 1; }
+
+// the tensor whose shape defines the device row layout (views share their source's rows)
+static const struct ggml_tensor * mi355_root(const struct ggml_tensor * t) { return t->view_src ? t->view_src : t; }
+
+// rows of a quantized tensor are stored planar iff (type, ne0) says so -- same predicate everywhere
+static bool mi355_rows_planar(const struct ggml_tensor * t) {
+    return mi355_is_quant(t->type) && mi355q_weights_are_planar((int) t->type, mi355_root(t)->ne[0]) == 1;
+}
+
+// ------------------------------------------------------------------------------------------------ buffer
+static void mi355_buffer_free(ggml_backend_buffer_t buffer) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *) buffer->context;
+    mi355q_set_device(ctx->device);
+    if (ctx->base) mi355q_free(ctx->base);
+    delete ctx;
+}
+
+static void * mi355_buffer_get_base(ggml_backend_buffer_t buffer) { return ((mi355_buffer_ctx *) buffer->context)->base; }
+
+static enum ggml_status mi355_buffer_init_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor) {
+    GGML_UNUSED(buffer); GGML_UNUSED(tensor);
+    return GGML_STATUS_SUCCESS;
+}
+
+static void mi355_buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *) buffer->context;
+    mi355q_set_device(ctx->device);
+    MQ_CHECK(mi355q_memset((char *) tensor->data + offset, value, size, nullptr));
+    MQ_CHECK(mi355q_device_synchronize());
+}
+
+// canonical host bytes [offset, offset+size) of `tensor` <-> device.  Quantized planar rows are converted in
+// whole rows; a range that is not row-aligned is widened to whole rows (read-modify-write on upload).
+static void mi355_buffer_transfer(mi355_buffer_ctx * ctx, const struct ggml_tensor * tensor, void * host, size_t offset, size_t size, bool upload) {
+    mi355q_set_device(ctx->device);
+    char * dev = (char *) tensor->data;
+    if (!mi355_rows_planar(tensor)) {
+        if (upload) MQ_CHECK(mi355q_memcpy_h2d(dev + offset, host, size, nullptr));
+        else        MQ_CHECK(mi355q_memcpy_d2h(host, dev + offset, size, nullptr));
+        return;
+    }
+    GGML_ASSERT(ggml_is_contiguous(tensor) && "MI355: planar quantized tensors are transferred as contiguous rows");
+    const int64_t k  = mi355_root(tensor)->ne[0];
+    const size_t  rb = (size_t) mi355q_row_size((int) tensor->type, k);
+    const size_t  r0 = offset / rb, r1 = (offset + size + rb - 1) / rb;
+    if (offset % rb == 0 && size % rb == 0) {
+        if (upload) MQ_CHECK(mi355q_weights_upload((int) tensor->type, dev + offset, host, (int64_t) (size / rb), k, nullptr));
+        else        MQ_CHECK(mi355q_weights_download((int) tensor->type, host, dev + offset, (int64_t) (size / rb), k, nullptr));
+        return;
+    }
+    std::vector<char> rows((r1 - r0) * rb);
+    MQ_CHECK(mi355q_weights_download((int) tensor->type, rows.data(), dev + r0 * rb, (int64_t) (r1 - r0), k, nullptr));
+    if (upload) {
+        memcpy(rows.data() + (offset - r0 * rb), host, size);
+        MQ_CHECK(mi355q_weights_upload((int) tensor->type, dev + r0 * rb, rows.data(), (int64_t) (r1 - r0), k, nullptr));
+    } else {
+        memcpy(host, rows.data() + (offset - r0 * rb), size);
+    }
+}
+
+static void mi355_buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi355_buffer_transfer((mi355_buffer_ctx *) buffer->context, tensor, (void *) data, offset, size, true);
+}
+
+static void mi355_buffer_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi355_buffer_transfer((mi355_buffer_ctx *) buffer->context, tensor, data, offset, size, false);
+}
+
+static bool mi355_buffer_is_ours(ggml_backend_buffer_t buffer) { return buffer && buffer->iface.get_base == mi355_buffer_get_base; }
+
+static bool mi355_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    // device-to-device only when both sides keep the same byte image (same type and row length)
+    if (!mi355_buffer_is_ours(src->buffer)) return false;
+    if (src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst) || ggml_nbytes(src) != ggml_nbytes(dst)) return false;
+    if (mi355_is_quant(src->type) && mi355_root(src)->ne[0] != mi355_root(dst)->ne[0]) return false;
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *) buffer->context;
+    mi355q_set_device(ctx->device);
+    MQ_CHECK(mi355q_memcpy_d2d(dst->data, src->data, ggml_nbytes(src), nullptr));
+    MQ_CHECK(mi355q_device_synchronize());
+    return true;
+}
+
+static void mi355_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *) buffer->context;
+    mi355q_set_device(ctx->device);
+    MQ_CHECK(mi355q_memset(ctx->base, value, buffer->size, nullptr));
+    MQ_CHECK(mi355q_device_synchronize());
+}
+
+static const struct ggml_backend_buffer_i mi355_buffer_iface = {
+    /* .free_buffer   = */ mi355_buffer_free,
+    /* .get_base      = */ mi355_buffer_get_base,
+    /* .init_tensor   = */ mi355_buffer_init_tensor,
+    /* .memset_tensor = */ mi355_buffer_memset_tensor,
+    /* .set_tensor    = */ mi355_buffer_set_tensor,
+    /* .get_tensor    = */ mi355_buffer_get_tensor,
+    /* .cpy_tensor    = */ mi355_buffer_cpy_tensor,
+    /* .clear         = */ mi355_buffer_clear,
+    /* .reset         = */ nullptr,
+};
+
+// ------------------------------------------------------------------------------------------------ buffer type
+static const char * mi355_buft_get_name(ggml_backend_buffer_type_t buft) { return ((mi355_device_ctx *) buft->device->context)->buft_name.c_str(); }
+
+static ggml_backend_buffer_t mi355_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    mi355_device_ctx * dev = (mi355_device_ctx *) buft->device->context;
+    mi355q_set_device(dev->index);
+    void * base = nullptr;
+    if (mi355q_malloc(&base, size + 256) != MI355Q_OK) {          // OOM is recoverable: the caller checks for NULL
+        GGML_LOG_ERROR("MI355: allocating %.2f MiB on device %d failed: %s\n", size / 1024.0 / 1024.0, dev->index, mi355q_last_error());
+        return nullptr;
+    }
+    mi355_buffer_ctx * ctx = new mi355_buffer_ctx{ dev->index, base };
+    return ggml_backend_buffer_init(buft, mi355_buffer_iface, ctx, size);
+}
+
+static size_t mi355_buft_get_alignment(ggml_backend_buffer_type_t buft) { GGML_UNUSED(buft); return 256; }   // >= 16 for the planar rows
+
+static const struct ggml_backend_buffer_type_i mi355_buft_iface = {
+    /* .get_name       = */ mi355_buft_get_name,
+    /* .alloc_buffer   = */ mi355_buft_alloc_buffer,
+    /* .get_alignment  = */ mi355_buft_get_alignment,
+    /* .get_max_size   = */ nullptr,
+    /* .get_alloc_size = */ nullptr,          // device rows have exactly the canonical size: ggml_nbytes is right
+    /* .is_host        = */ nullptr,
+};
+
+static bool mi355_buft_is_ours(ggml_backend_buffer_type_t buft) { return buft && buft->iface.get_name == mi355_buft_get_name; }
+
+// ------------------------------------------------------------------------------------------------ the ops
+static void * mi355_workspace(mi355_backend_ctx * ctx, size_t bytes) {
+    if (bytes <= ctx->workspace_size) return ctx->workspace;
+    MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+    if (ctx->workspace) mi355q_free(ctx->workspace);
+    const size_t want = bytes + (bytes >> 2) + (1u << 20);
+    MQ_CHECK(mi355q_malloc(&ctx->workspace, want));
+    ctx->workspace_size = want;
+    return ctx->workspace;
+}
+
+// GGML_OP_MUL_MAT (ggml.c:2730-2745; CPU semantics ggml-cpu.c:1266-1458): dst[ne01, ne11, ne12, ne13],
+// src0 broadcast over dims 2/3 with r2 = ne12/ne02, r3 = ne13/ne03.
+static void mi355_mul_mat(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
+    const struct ggml_tensor * src0 = dst->src[0];
+    const struct ggml_tensor * src1 = dst->src[1];
+    const int64_t K = src0->ne[0], M = src0->ne[1], N = src1->ne[1];
+    const int64_t r2 = src1->ne[2] / src0->ne[2], r3 = src1->ne[3] / src0->ne[3];
+    const size_t  ws = mi355q_mul_mat_workspace((int) src0->type, M, N, K);
+    void * wsp = ws ? mi355_workspace(ctx, ws) : nullptr;
+    for (int64_t i13 = 0; i13 < src1->ne[3]; ++i13) {
+        for (int64_t i12 = 0; i12 < src1->ne[2]; ++i12) {
+            const char * w = (const char *) src0->data + (i12 / r2) * src0->nb[2] + (i13 / r3) * src0->nb[3];
+            const char * x = (const char *) src1->data + i12 * src1->nb[2] + i13 * src1->nb[3];
+            char *       y = (char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3];
+            MQ_CHECK(mi355q_mul_mat((int) src0->type, w, (int64_t) src0->nb[1], (const float *) x, (int64_t) src1->nb[1],
+                                    (float *) y, (int64_t) dst->nb[1], M, N, K, wsp, ws, 0, ctx->stream));
+        }
+    }
+}
+
+// GGML_OP_MUL_MAT_ID (ggml.c:2771-2796; CPU ggml-cpu.c:1540-1718): as [K, M, n_expert], b [K, n_used|1, n_tok],
+// ids i32 [n_used, n_tok] -> dst [M, n_used, n_tok].  The ids stay on the device (no host sync, cf. ggml-cuda.cu:2008-2011).
+static void mi355_mul_mat_id(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
+    const struct ggml_tensor * as  = dst->src[0];
+    const struct ggml_tensor * b   = dst->src[1];
+    const struct ggml_tensor * ids = dst->src[2];
+    const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
+    const int64_t n_used = ids->ne[0], n_tok = ids->ne[1], b_ne1 = b->ne[1];
+    const size_t  ws = mi355q_mul_mat_id_workspace((int) as->type, M, K, n_used, n_tok, b_ne1);
+    void * wsp = ws ? mi355_workspace(ctx, ws) : nullptr;
+    MQ_CHECK(mi355q_mul_mat_id((int) as->type, as->data, (int64_t) as->nb[1], (int64_t) as->nb[2], n_expert,
+                               (const float *) b->data, b_ne1, (int64_t) b->nb[1], (int64_t) b->nb[2],
+                               (const int32_t *) ids->data, (int64_t) ids->nb[1],
+                               (float *) dst->data, M, K, n_used, n_tok, wsp, ws, 0, ctx->stream));
+}
+
+// ------------------------------------------------------------------------------------------------ backend (stream)
+static const char * mi355_backend_get_name(ggml_backend_t backend) { return ((mi355_backend_ctx *) backend->context)->name.c_str(); }
+
+static void mi355_backend_free(ggml_backend_t backend) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    mi355q_set_device(ctx->device);
+    if (ctx->stream) { mi355q_stream_synchronize(ctx->stream); mi355q_stream_destroy(ctx->stream); }
+    if (ctx->workspace) mi355q_free(ctx->workspace);
+    delete ctx;
+    delete backend;
+}
+
+static void mi355_backend_synchronize(ggml_backend_t backend) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    mi355q_set_device(ctx->device);
+    MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+}
+
+static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    mi355q_set_device(ctx->device);
+    for (int i = 0; i < cgraph->n_nodes; ++i) {
+        struct ggml_tensor * node = cgraph->nodes[i];
+        if (ggml_is_empty(node)) continue;
+        switch (node->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            break;
+        case GGML_OP_MUL_MAT:    mi355_mul_mat(ctx, node);    break;
+        case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
+        default:
+            GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
+            return GGML_STATUS_FAILED;
+        }
+    }
+    // set_tensor/get_tensor of this backend are synchronous copies on the null stream: finish the work before returning
+    MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+    return GGML_STATUS_SUCCESS;
+}
+
+static const struct ggml_backend_i mi355_backend_iface = {
+    /* .get_name           = */ mi355_backend_get_name,
+    /* .free               = */ mi355_backend_free,
+    /* .set_tensor_async   = */ nullptr,
+    /* .get_tensor_async   = */ nullptr,
+    /* .cpy_tensor_async   = */ nullptr,
+    /* .synchronize        = */ mi355_backend_synchronize,
+    /* .graph_plan_create  = */ nullptr,
+    /* .graph_plan_free    = */ nullptr,
+    /* .graph_plan_update  = */ nullptr,
+    /* .graph_plan_compute = */ nullptr,
+    /* .graph_compute      = */ mi355_backend_graph_compute,
+    /* .event_record       = */ nullptr,
+    /* .event_wait         = */ nullptr,
+};
+
+// ------------------------------------------------------------------------------------------------ device
+static const char * mi355_dev_get_name(ggml_backend_dev_t dev) { return ((mi355_device_ctx *) dev->context)->name.c_str(); }
+static const char * mi355_dev_get_description(ggml_backend_dev_t dev) { return ((mi355_device_ctx *) dev->context)->description.c_str(); }
+
+static void mi355_dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    mi355_device_ctx * ctx = (mi355_device_ctx *) dev->context;
+    size_t f = 0, t = 0;
+    mi355q_device_info(ctx->index, nullptr, 0, &f, &t, nullptr);
+    *free = f; *total = t;                       // real numbers: they drive the layer-split ratios (llama-model.cpp:1441-1449)
+}
+
+static enum ggml_backend_dev_type mi355_dev_get_type(ggml_backend_dev_t dev) { GGML_UNUSED(dev); return GGML_BACKEND_DEVICE_TYPE_GPU; }
+
+static void mi355_dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_props * props) {
+    props->name = mi355_dev_get_name(dev);
+    props->description = mi355_dev_get_description(dev);
+    props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
+    mi355_dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false };
+}
+
+static ggml_backend_t mi355_dev_init_backend(ggml_backend_dev_t dev, const char * params) {
+    GGML_UNUSED(params);
+    mi355_device_ctx * dctx = (mi355_device_ctx *) dev->context;
+    if (mi355q_set_device(dctx->index) != MI355Q_OK) {
+        GGML_LOG_ERROR("MI355: cannot select device %d: %s\n", dctx->index, mi355q_last_error());
+        return nullptr;
+    }
+    mi355_backend_ctx * ctx = new mi355_backend_ctx;
+    ctx->device = dctx->index;
+    ctx->name = dctx->name;
+    if (mi355q_stream_create(&ctx->stream) != MI355Q_OK) {
+        GGML_LOG_ERROR("MI355: stream creation failed: %s\n", mi355q_last_error());
+        delete ctx;
+        return nullptr;
+    }
+    return new ggml_backend{ /* .guid = */ mi355_guid(), /* .iface = */ mi355_backend_iface, /* .device = */ dev, /* .context = */ ctx };
+}
+
+static ggml_backend_buffer_type_t mi355_dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi355_device_ctx *) dev->context)->buft; }
+
+// a tensor we can read as an operand: lives in one of OUR buffers (or is not placed yet / is the loader's
+// zero-size probe buffer, llama-model.cpp:236-241 -- only buffer->buft may be looked at there)
+static bool mi355_operand_ok(const struct ggml_tensor * t) {
+    return t->buffer == nullptr || mi355_buft_is_ours(t->buffer->buft);
+}
+
+static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tensor * op) {
+    GGML_UNUSED(dev);
+    switch (op->op) {
+    case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+        return true;
+    case GGML_OP_MUL_MAT: {
+        const struct ggml_tensor * a = op->src[0];
+        const struct ggml_tensor * b = op->src[1];
+        if (!mi355_is_quant(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+        if (!mi355_operand_ok(a)) return false;
+        // src0: whole rows of its root tensor, rows dense, 16-byte aligned row pitch where the rows are planar
+        if (a->nb[0] != ggml_type_size(a->type) || mi355_root(a)->ne[0] != a->ne[0]) return false;
+        if (a->nb[1] < ggml_row_size(a->type, a->ne[0])) return false;
+        if (mi355q_weights_are_planar((int) a->type, a->ne[0]) && (a->nb[1] % 16 || a->nb[2] % 16 || a->nb[3] % 16)) return false;
+        // src1 / dst: rows contiguous (any row pitch); permuted activations stay on the CPU
+        if (b->nb[0] != sizeof(float) || b->nb[1] < b->ne[0] * sizeof(float)) return false;
+        if (op->nb[0] != sizeof(float) || !ggml_is_contiguous(op)) return false;
+        if (b->ne[1] > 65535) return false;
+        return true;
+    }
+    case GGML_OP_MUL_MAT_ID: {
+        const struct ggml_tensor * a = op->src[0];
+        const struct ggml_tensor * b = op->src[1];
+        const struct ggml_tensor * ids = op->src[2];
+        if (!mi355_is_quant(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32) return false;
+        if (!mi355_operand_ok(a)) return false;
+        if (!ggml_is_contiguous(a) || a->view_src) return false;
+        if (b->nb[0] != sizeof(float) || !ggml_is_contiguous(op) || ids->nb[0] != sizeof(int32_t)) return false;
+        if (ids->ne[0] * ids->ne[1] > 65535) return false;
+        return true;
+    }
+    default:
+        return false;
+    }
+}
+
+static bool mi355_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    return mi355_buft_is_ours(buft) && buft->device == dev;
+}
+
+static const struct ggml_backend_device_i mi355_device_iface = {
+    /* .get_name             = */ mi355_dev_get_name,
+    /* .get_description      = */ mi355_dev_get_description,
+    /* .get_memory           = */ mi355_dev_get_memory,
+    /* .get_type             = */ mi355_dev_get_type,
+    /* .get_props            = */ mi355_dev_get_props,
+    /* .init_backend         = */ mi355_dev_init_backend,
+    /* .get_buffer_type      = */ mi355_dev_get_buffer_type,
+    /* .get_host_buffer_type = */ nullptr,
+    /* .buffer_from_host_ptr = */ nullptr,
+    /* .supports_op          = */ mi355_dev_supports_op,
+    /* .supports_buft        = */ mi355_dev_supports_buft,
+    /* .offload_op           = */ nullptr,
+    /* .event_new            = */ nullptr,
+    /* .event_free           = */ nullptr,
+    /* .event_synchronize    = */ nullptr,
+};
+
+// ------------------------------------------------------------------------------------------------ registry
+struct mi355_reg_ctx {
+    std::vector<ggml_backend_device *> devices;
+};
+
+static const char * mi355_reg_get_name(ggml_backend_reg_t reg) { GGML_UNUSED(reg); return "MI355"; }
+static size_t mi355_reg_get_device_count(ggml_backend_reg_t reg) { return ((mi355_reg_ctx *) reg->context)->devices.size(); }
+static ggml_backend_dev_t mi355_reg_get_device(ggml_backend_reg_t reg, size_t index) {
+    mi355_reg_ctx * ctx = (mi355_reg_ctx *) reg->context;
+    GGML_ASSERT(index < ctx->devices.size());
+    return ctx->devices[index];
+}
+static void * mi355_reg_get_proc_address(ggml_backend_reg_t reg, const char * name) {
+    GGML_UNUSED(reg); GGML_UNUSED(name);
+    return nullptr;      // no split buffers / n_threads / extra buffer types: NULL is the documented "not provided"
+}
+
+static const struct ggml_backend_reg_i mi355_reg_iface = {
+    /* .get_name         = */ mi355_reg_get_name,
+    /* .get_device_count = */ mi355_reg_get_device_count,
+    /* .get_device       = */ mi355_reg_get_device,
+    /* .get_proc_address = */ mi355_reg_get_proc_address,
+};
+
+extern "C" {
+GGML_BACKEND_API ggml_backend_reg_t ggml_backend_mi355_reg(void);
+}
+
+ggml_backend_reg_t ggml_backend_mi355_reg(void) {
+    static std::mutex mutex;
+    static bool initialized = false;
+    static struct ggml_backend_reg reg;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (!initialized) {
+        mi355_reg_ctx * ctx = new mi355_reg_ctx;
+        int n = mi355q_device_count();
+        if (n > MI355_MAX_DEVICES) n = MI355_MAX_DEVICES;
+        for (int i = 0; i < n; ++i) {
+            mi355_device_ctx * dctx = new mi355_device_ctx;
+            dctx->index = i;
+            dctx->name = "MI355_" + std::to_string(i);
+            char desc[256] = "AMD Instinct MI355X";
+            mi355q_device_info(i, desc, sizeof(desc), nullptr, nullptr, nullptr);
+            dctx->description = desc;
+            dctx->buft_name = dctx->name;
+            ggml_backend_device * dev = new ggml_backend_device{ /* .iface = */ mi355_device_iface, /* .reg = */ &reg, /* .context = */ dctx };
+            dctx->buft = { /* .iface = */ mi355_buft_iface, /* .device = */ dev, /* .context = */ nullptr };
+            ctx->devices.push_back(dev);
+        }
+        reg = { /* .api_version = */ GGML_BACKEND_API_VERSION, /* .iface = */ mi355_reg_iface, /* .context = */ ctx };
+        initialized = true;
+    }
+    return &reg;
+}
+
+static int ggml_backend_mi355_score(void) { return mi355q_device_count() > 0 ? 100 : 0; }
+
+GGML_BACKEND_DL_IMPL(ggml_backend_mi355_reg)
+GGML_BACKEND_DL_SCORE_IMPL(ggml_backend_mi355_score)

@@ -1,0 +1,68 @@
+"""The ggml backend plugin (libggml-mi355.so) -- the drop-in boundary the reference's own tools load.
+
+CPU part: the shared object exists after build() (where the reference headers are available), exports the
+two dynamic-loading entry points of ggml-backend-impl.h:215-251, and the reference's test-backend-ops
+loads it through GGML_BACKEND_PATH without a GPU (no device is enumerated, nothing crashes).
+
+GPU part: the reference's OWN op-parity harness (tests/test-backend-ops.cpp, compiled unmodified from
+/root/reference into oracle/_ref/) drives the plugin against the ggml CPU backend: every MUL_MAT and
+MUL_MAT_ID case it generates must pass its NMSE <= 5e-4 check (test-backend-ops.cpp:1990-1992, 2083-2085)
+or be reported "not supported"; none may fail."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import oracle
+from conftest import ROOT
+
+PLUGIN = ROOT / "llama.cpp.dsp_amd" / "lib" / "libggml-mi355.so"
+
+
+def _harness():
+    v = oracle.best_ref_variant()
+    if v is None:
+        return None
+    p = ROOT / "oracle" / "_ref" / v / "test-backend-ops"
+    return p if p.exists() else None
+
+
+def _run(args, timeout=900):
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN))
+    return subprocess.run([str(_harness())] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+needs_plugin = pytest.mark.skipif(not PLUGIN.exists() or _harness() is None, reason="plugin or oracle/_ref not built")
+
+
+@needs_plugin
+def test_plugin_exports_dl_entry_points():
+    out = subprocess.run(["nm", "-D", "--defined-only", str(PLUGIN)], capture_output=True, text=True).stdout
+    assert re.search(r"\bT ggml_backend_init\b", out) and re.search(r"\bT ggml_backend_score\b", out)
+
+
+@needs_plugin
+def test_reference_harness_loads_plugin_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = _run(["test", "-o", "MUL_MAT"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "MI355" not in r.stdout            # no gfx950 device here -> nothing enumerated, CPU only
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("op", ["MUL_MAT", "MUL_MAT_ID"])
+def test_reference_test_backend_ops(op):
+    r = _run(["test", "-b", "MI355_0", "-o", op])
+    tail = r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+)/(\d+) tests passed", r.stdout)
+    assert m and m.group(1) == m.group(2), tail
+    assert "Backend MI355_0: " in r.stdout and "OK" in r.stdout, tail
+    assert "FAIL" not in r.stdout
+    ran = len(re.findall(r"\bOK\b", r.stdout)); unsupported = r.stdout.count("not supported")
+    print(f"{op}: {m.group(1)} cases, {unsupported} reported not supported")
+    assert ran > 100                          # the quantized cases really ran on the device
