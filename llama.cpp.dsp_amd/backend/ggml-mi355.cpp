@@ -106,22 +106,25 @@ static void mi355_buffer_transfer(mi355_buffer_ctx * ctx, const struct ggml_tens
         else        MQ_CHECK(mi355q_memcpy_d2h(host, dev + offset, size, nullptr));
         return;
     }
-    GGML_ASSERT(ggml_is_contiguous(tensor) && "MI355: planar quantized tensors are transferred as contiguous rows");
-    const int64_t k  = mi355_root(tensor)->ne[0];
-    const size_t  rb = (size_t) mi355q_row_size((int) tensor->type, k);
-    const size_t  r0 = offset / rb, r1 = (offset + size + rb - 1) / rb;
-    if (offset % rb == 0 && size % rb == 0) {
-        if (upload) MQ_CHECK(mi355q_weights_upload((int) tensor->type, dev + offset, host, (int64_t) (size / rb), k, nullptr));
-        else        MQ_CHECK(mi355q_weights_download((int) tensor->type, host, dev + offset, (int64_t) (size / rb), k, nullptr));
+    // The byte range is addressed in MEMORY order (that is what set/get on a permuted view means, cf.
+    // tests/test-backend-ops.cpp init of permuted src0): rows are the root tensor's rows, wherever the view points.
+    const int64_t k    = mi355_root(tensor)->ne[0];
+    const size_t  rb   = (size_t) mi355q_row_size((int) tensor->type, k);
+    char *        base = (char *) mi355_root(tensor)->data;
+    const size_t  beg  = (size_t) (dev - base) + offset, end = beg + size;
+    const size_t  r0 = beg / rb, r1 = (end + rb - 1) / rb;
+    if (beg % rb == 0 && size % rb == 0) {
+        if (upload) MQ_CHECK(mi355q_weights_upload((int) tensor->type, base + beg, host, (int64_t) (size / rb), k, nullptr));
+        else        MQ_CHECK(mi355q_weights_download((int) tensor->type, host, base + beg, (int64_t) (size / rb), k, nullptr));
         return;
     }
     std::vector<char> rows((r1 - r0) * rb);
-    MQ_CHECK(mi355q_weights_download((int) tensor->type, rows.data(), dev + r0 * rb, (int64_t) (r1 - r0), k, nullptr));
+    MQ_CHECK(mi355q_weights_download((int) tensor->type, rows.data(), base + r0 * rb, (int64_t) (r1 - r0), k, nullptr));
     if (upload) {
-        memcpy(rows.data() + (offset - r0 * rb), host, size);
-        MQ_CHECK(mi355q_weights_upload((int) tensor->type, dev + r0 * rb, rows.data(), (int64_t) (r1 - r0), k, nullptr));
+        memcpy(rows.data() + (beg - r0 * rb), host, size);
+        MQ_CHECK(mi355q_weights_upload((int) tensor->type, base + r0 * rb, rows.data(), (int64_t) (r1 - r0), k, nullptr));
     } else {
-        memcpy(host, rows.data() + (offset - r0 * rb), size);
+        memcpy(host, rows.data() + (beg - r0 * rb), size);
     }
 }
 

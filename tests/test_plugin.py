@@ -61,8 +61,15 @@ def test_reference_test_backend_ops(op):
     assert r.returncode == 0, tail
     m = re.search(r"(\d+)/(\d+) tests passed", r.stdout)
     assert m and m.group(1) == m.group(2), tail
-    assert "Backend MI355_0: " in r.stdout and "OK" in r.stdout, tail
+    assert "Backend 2/2: MI355_0" in r.stdout and "2/2 backends passed" in r.stdout, tail
     assert "FAIL" not in r.stdout
-    ran = len(re.findall(r"\bOK\b", r.stdout)); unsupported = r.stdout.count("not supported")
-    print(f"{op}: {m.group(1)} cases, {unsupported} reported not supported")
-    assert ran > 100                          # the quantized cases really ran on the device
+    cases = [l for l in r.stdout.splitlines() if l.lstrip().startswith(op + "(")]
+    ran = [l for l in cases if "OK" in l]
+    unsupported = [l for l in cases if "not supported" in l]
+    print(f"{op}: {len(ran)} cases ran on MI355_0 and passed, {len(unsupported)} reported not supported")
+    assert len(ran) + len(unsupported) == len(cases)
+    assert len(ran) >= 150                      # the quantized cases really ran on the device
+    # every case of the 12 implemented weight types with f32 activations must have RUN (not been skipped)
+    for t in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_K", "q3_K", "q4_K", "q5_K", "q6_K", "iq4_nl", "iq4_xs"):
+        mine = [l for l in cases if f"type_a={t}," in l and "type_b=f32" in l]
+        assert mine and all("OK" in l for l in mine if "per=[0,1,2,3]" in l and "v=0" in l), t
