@@ -19,6 +19,16 @@ int launch_gemv_fast(const mi355q_mat * mats, int n_mats, const float * x, int64
 int gemv_fast_family(int type);
 int gemv_fast_max_cols(int type, int64_t k);
 int launch_pack(int type, void * dst, const void * src, int64_t nrows, int64_t k, bool pack, hipStream_t stream);
+bool mmq_supported(int type, int64_t k);
+size_t mmq_workspace(int64_t n, int64_t k);
+int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
+                    int64_t m, int64_t n, int64_t k, void * workspace, hipStream_t stream);
+
+// tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
+static bool use_mmq(int type, int64_t n, int64_t k, int flags) {
+    if (!mmq_supported(type, k) || (flags & MI355Q_FLAG_FORCE_GEMV)) return false;
+    return n > 8 || (flags & MI355Q_FLAG_FORCE_MMQ);
+}
 
 static thread_local char t_err[512] = "";
 static int fail(int code, const char * fmt, ...) {
@@ -170,7 +180,7 @@ size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k) {
     (void) m;
     const TypeInfo * t = type_info(type);
     if (!t || t->act < 0 || k % t->blck) return 0;
-    if (is_planar(t, k)) return 0;                                    // fused prologue: no scratch
+    if (is_planar(t, k)) return mmq_supported(type, k) ? mmq_workspace(n, k) : 0;   // GEMV tier: fused prologue, no scratch; MFMA tier: bf16 activations
     return (size_t) align256(mi355q_row_size(t->act, k) * n);
 }
 
@@ -204,6 +214,16 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
         if (fam < 0) fam = f;
     }
     if (n == 0) return MI355Q_OK;
+    if (all_fast && use_mmq(mats[0].type, n, k, flags)) {
+        // MFMA tier (prefill): one launch per matrix; rows that break its alignment contract drop to the GEMV tier
+        bool ok = workspace && workspace_bytes >= mmq_workspace(n, k);
+        for (int i = 0; i < n_mats && ok; ++i) ok = mmq_supported(mats[i].type, k) && !(((uintptr_t) mats[i].y | (uintptr_t) mats[i].y_stride) & 15);
+        if (ok) {
+            for (int i = 0; i < n_mats; ++i)
+                MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, st));
+            return MI355Q_OK;
+        }
+    }
     if (all_fast) {
         // GEMV tier, tiled over activation columns (each tile re-streams W; the MFMA tier takes over for large n)
         const int maxc = gemv_fast_max_cols(mats[0].type, k);
