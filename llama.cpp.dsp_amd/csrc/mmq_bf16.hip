@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float  f32x2;
 typedef __attribute__((ext_vector_type(4))) float  f32x4;
 
-constexpr int MMQ_BM = 128, MMQ_BN = 128, MMQ_BK = 128, MMQ_THREADS = 256;
+constexpr int MMQ_BM = 128, MMQ_BK = 128, MMQ_THREADS = 256;   // BN (tokens per tile) is a template parameter: 128 or 64
 constexpr int MMQ_LDS_STRIDE = (MMQ_BK + 8) * 2;          // bytes per LDS row (16-byte pad)
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -189,15 +189,16 @@ template <> struct W64<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]
 };
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <int T>
+template <int T, int MMQ_BN>
 __global__ void __launch_bounds__(MMQ_THREADS, 2)
 k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __restrict__ xb /* bf16 [n][k] */,
            float * __restrict__ y, int64_t y_stride, int m, int n, int k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // 2 * 128 * 272 B = 68 KiB (> the 64 KiB static limit)
     uint8_t * Ws = lds;
-    uint8_t * Xs = lds + MMQ_BM * MMQ_LDS_STRIDE;
+    uint8_t * Xs = lds + MMQ_BM * MMQ_LDS_STRIDE;                          // BN rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                              // 2 x 2 waves, 64 x 64 each
+    const int wm = wave >> 1, wn = wave & 1;                              // 2 x 2 waves, 64 x (BN/2) each
+    constexpr int WN = MMQ_BN / 2, NT = WN / 16;                          // tokens per wave, 16-token MFMA tiles per wave
     const int m0 = blockIdx.x * MMQ_BM, n0 = blockIdx.y * MMQ_BN;
     const int nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
     const int steps = k / MMQ_BK;
@@ -208,14 +209,14 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
     const uint8_t * wrow = w + (int64_t) (wvalid ? m0 + wr : 0) * w_stride;
     // this thread's activation staging job: token n0 + tid/2, 64 k (128 B) at k half tid%2
     const int  xr = tid >> 1, xsub = tid & 1;
-    const bool xvalid = n0 + xr < n;
+    const bool xvalid = xr < MMQ_BN && n0 + xr < n;
     const uint16_t * xrow = xb + (int64_t) (xvalid ? n0 + xr : 0) * k + 64 * xsub;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4) { 0.f, 0.f, 0.f, 0.f };
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4) { 0.f, 0.f, 0.f, 0.f };
 
     W64<T> wq;
     uint4 xv[8];
@@ -240,9 +241,11 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
                 v.z = pack_bf16(wf[8 * i + 4], wf[8 * i + 5]); v.w = pack_bf16(wf[8 * i + 6], wf[8 * i + 7]);
                 *(uint4 *) (dst + 16 * i) = v;
             }
-            uint8_t * xdst = Xs + xr * MMQ_LDS_STRIDE + 128 * xsub;
+            if (xr < MMQ_BN) {
+                uint8_t * xdst = Xs + xr * MMQ_LDS_STRIDE + 128 * xsub;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *(uint4 *) (xdst + 16 * i) = xv[i];
+                for (int i = 0; i < 8; ++i) *(uint4 *) (xdst + 16 * i) = xv[i];
+            }
         }
         __syncthreads();
         // ---- prefetch step ks+1 while the matrix cores work on step ks ----
@@ -254,24 +257,24 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
         // ---- 4 k-slices of 32: A = W rows (lane: row l&15, k 8*(l>>4)..+7), B = tokens (lane: col l&15, same k) ----
 #pragma unroll
         for (int kk = 0; kk < MMQ_BK / 32; ++kk) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[NT];
             const int koff = 2 * (32 * kk + 8 * (lane >> 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i]  = *(const bf16x8 *) (Ws + (64 * wm + 16 * i + (lane & 15)) * MMQ_LDS_STRIDE + koff);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8 *) (Xs + (64 * wn + 16 * j + (lane & 15)) * MMQ_LDS_STRIDE + koff);
+            for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8 *) (Xs + (WN * wn + 16 * j + (lane & 15)) * MMQ_LDS_STRIDE + koff);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane&15 (token), row = 4*(lane>>4) + reg (weight row): 4 consecutive m per lane ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int tok = n0 + 64 * wn + 16 * j + (lane & 15);
+    for (int j = 0; j < NT; ++j) {
+        const int tok = n0 + WN * wn + 16 * j + (lane & 15);
         if (tok >= n) continue;
         float * yr = (float *) ((char *) y + (int64_t) tok * y_stride);
 #pragma unroll
@@ -299,30 +302,36 @@ size_t mmq_workspace(int64_t n, int64_t k) { return (size_t) (n * k * 2 + 255) &
 
 // w: planar device rows; x f32 [n][k] (row stride x_stride); workspace >= mmq_workspace(n,k); y f32 [n][m] (y_stride % 16 == 0)
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, hipStream_t stream) {
+                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream) {
     if (!mmq_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (m <= 0 || n <= 0) return MI355Q_OK;
     if ((y_stride & 15) || ((uintptr_t) y & 15)) return MI355Q_ERR_ALIGN;
     const int64_t pairs = n * k / 2;
     const int cgrid = (int) ((pairs + 255) / 256 < 8192 ? (pairs + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_x_to_bf16, dim3(cgrid), dim3(256), 0, stream, x, x_stride, (uint32_t *) workspace, n, k);
-    const dim3 grid((unsigned) ((m + MMQ_BM - 1) / MMQ_BM), (unsigned) ((n + MMQ_BN - 1) / MMQ_BN));
-    constexpr size_t lds_bytes = 2 * MMQ_BM * MMQ_LDS_STRIDE;
-#define MI355Q_MMQ_CASE(T) case T: {                                                                                               \
+    // 128-token tiles amortize the dequantization best; when that leaves CUs idle (M = 4096, N = 512 is only 128 tiles
+    // for 256 CUs) use 64-token tiles.
+    const int64_t tiles128 = ((m + MMQ_BM - 1) / MMQ_BM) * ((n + 127) / 128);
+    const int bn = (tiles128 < (int64_t) n_cu && n > 64) ? 64 : 128;
+    const dim3 grid((unsigned) ((m + MMQ_BM - 1) / MMQ_BM), (unsigned) ((n + bn - 1) / bn));
+#define MI355Q_MMQ_LAUNCH(T, BN) {                                                                                                 \
+        constexpr size_t lds_bytes = (size_t) (MMQ_BM + BN) * MMQ_LDS_STRIDE;                                                      \
         static bool attr_set = false;                                                                                              \
         if (!attr_set) {                                                                                                           \
-            if (hipFuncSetAttribute((const void *) k_mmq_bf16<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess) \
+            if (hipFuncSetAttribute((const void *) k_mmq_bf16<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess) \
                 return MI355Q_ERR_HIP;                                                                                             \
             attr_set = true;                                                                                                       \
         }                                                                                                                          \
-        hipLaunchKernelGGL((k_mmq_bf16<T>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,             \
-                           (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k); } break;
+        hipLaunchKernelGGL((k_mmq_bf16<T, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,         \
+                           (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k); }
+#define MI355Q_MMQ_CASE(T) case T: if (bn == 64) MI355Q_MMQ_LAUNCH(T, 64) else MI355Q_MMQ_LAUNCH(T, 128) break;
     switch (type) {
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q5_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q6_K)
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q8_0) MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_0)
     default: return MI355Q_ERR_UNSUPPORTED;
     }
 #undef MI355Q_MMQ_CASE
+#undef MI355Q_MMQ_LAUNCH
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
 }
 
