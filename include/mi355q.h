@@ -70,8 +70,15 @@ extern "C" {
 #define MI355Q_TYPE_Q5_K   13
 #define MI355Q_TYPE_Q6_K   14
 #define MI355Q_TYPE_Q8_K   15
-#define MI355Q_TYPE_IQ4_NL 20
-#define MI355Q_TYPE_IQ4_XS 23
+#define MI355Q_TYPE_IQ2_XXS 16
+#define MI355Q_TYPE_IQ2_XS  17
+#define MI355Q_TYPE_IQ3_XXS 18
+#define MI355Q_TYPE_IQ1_S   19
+#define MI355Q_TYPE_IQ4_NL  20
+#define MI355Q_TYPE_IQ3_S   21
+#define MI355Q_TYPE_IQ2_S   22
+#define MI355Q_TYPE_IQ4_XS  23
+#define MI355Q_TYPE_IQ1_M   29
 
 /* flags for mi355q_mul_mat* / mi355q_quantize_act */
 #define MI355Q_FLAG_ROUND_AWAY   0x0  /* Q8_0/Q8_1 activations: q = roundf(x/d)   (quantize_row_q8_0_ref; default) */

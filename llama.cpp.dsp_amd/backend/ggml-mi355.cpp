@@ -7,7 +7,7 @@
 // backend :87-124) in plain C++ over the C-ABI of libmi355q.so (include/mi355q.h): no HIP code here.
 //
 // Scope: the quantized MUL_MAT / MUL_MAT_ID hot path.  supports_op is true for
-//   * GGML_OP_MUL_MAT    with quantized src0 (the 12 types of mi355q_type_supported), f32 src1, f32 dst
+//   * GGML_OP_MUL_MAT    with quantized src0 (the 19 types of mi355q_type_supported), f32 src1, f32 dst
 //   * GGML_OP_MUL_MAT_ID with the same src0 types
 //   * the no-op view ops NONE / RESHAPE / VIEW / PERMUTE / TRANSPOSE on our own buffers
 // everything else stays on the CPU backend.  The fork's own DSP backend (ggml/src/ggml-dsp/ggml-dsp.cpp)

@@ -7,6 +7,7 @@
 // (ggml-cpu-quants.c, scalar tails cited per type below).  Used for (type,K) pairs that have no
 // planar fast kernel; it is NOT the roofline path (byte loads, no unrolling).
 #include "mi355q_common.h"
+#include "iq_tables.h"   // code books of the IQ2/IQ3/IQ1 formats, derived by probing the reference decoder (tools/gen_iq_tables.py)
 
 namespace mi355q {
 
@@ -121,6 +122,87 @@ __device__ __forceinline__ float sub_dot(const uint8_t * wrow, const uint8_t * a
             }
             const float dall = yd * ld_h(w + 80), dmin = yd * ld_h(w + 82);
             return dall * (float) ((s0 & 0x0F) * sa + (s1 & 0x0F) * sb) - dmin * (float) ((s0 >> 4) * bs0 + (s1 >> 4) * bs1);
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ2_XXS) {          // :9834-9862   block: d(2) qs u16[32]
+            const uint8_t * w = wrow + b * 66; const uint8_t * q2 = w + 2 + 8 * j;
+            const uint32_t aux1 = (uint32_t) q2[4] | ((uint32_t) q2[5] << 8) | ((uint32_t) q2[6] << 16) | ((uint32_t) q2[7] << 24);
+            int sumi = 0;
+            for (int l = 0; l < 4; ++l) {
+                const uint8_t * g = c_grid_iq2xxs[q2[l]]; const uint32_t sg = c_signs_iq2[(aux1 >> (7 * l)) & 127];
+                for (int t = 0; t < 8; ++t) sumi += (int) g[t] * y[8 * l + t] * (((sg >> t) & 1) ? -1 : 1);
+            }
+            return 0.125f * ((ld_h(w) * yd) * (float) (sumi * (2 * (int) (aux1 >> 28) + 1)));
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ2_XS) {           // :10411-10447 block: d(2) qs u16[32] scales[8]
+            const uint8_t * w = wrow + b * 74; const uint8_t * q2 = w + 2 + 8 * j; const int sc = w[66 + j];
+            int s1 = 0, s2 = 0;
+            for (int l = 0; l < 4; ++l) {
+                const uint32_t q = (uint32_t) q2[2 * l] | ((uint32_t) q2[2 * l + 1] << 8);
+                const uint8_t * g = c_grid_iq2xs[q & 511]; const uint32_t sg = c_signs_iq2[q >> 9];
+                int t0 = 0;
+                for (int t = 0; t < 8; ++t) t0 += (int) g[t] * y[8 * l + t] * (((sg >> t) & 1) ? -1 : 1);
+                if (l < 2) s1 += t0; else s2 += t0;
+            }
+            return 0.125f * ((ld_h(w) * yd) * (float) (s1 * (2 * (sc & 0xf) + 1) + s2 * (2 * (sc >> 4) + 1)));
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ2_S) {            // :10885-10921 block: d(2) qs[32] signs[32] qh[8] scales[8]
+            const uint8_t * w = wrow + b * 82; const uint8_t * qs = w + 2 + 4 * j; const uint8_t * sg = w + 34 + 4 * j;
+            const int qh = w[66 + j], sc = w[74 + j];
+            int s1 = 0, s2 = 0;
+            for (int l = 0; l < 4; ++l) {
+                const uint8_t * g = c_grid_iq2s[qs[l] | ((qh << (8 - 2 * l)) & 0x300)];
+                int t0 = 0;
+                for (int t = 0; t < 8; ++t) t0 += y[8 * l + t] * (int) g[t] * (((sg[l] >> t) & 1) ? -1 : 1);
+                if (l < 2) s1 += t0; else s2 += t0;
+            }
+            return 0.125f * ((ld_h(w) * yd) * (float) ((1 + 2 * (sc & 0xf)) * s1 + (1 + 2 * (sc >> 4)) * s2));
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ3_XXS) {          // :11218-11247 block: d(2) qs[64] scales_and_signs[32]
+            const uint8_t * w = wrow + b * 98; const uint8_t * q3 = w + 2 + 8 * j; const uint8_t * gas = w + 66 + 4 * j;
+            const uint32_t aux = (uint32_t) gas[0] | ((uint32_t) gas[1] << 8) | ((uint32_t) gas[2] << 16) | ((uint32_t) gas[3] << 24);
+            int sumi = 0;
+            for (int l = 0; l < 4; ++l) {
+                const uint8_t * g1 = c_grid_iq3xxs[q3[2 * l]]; const uint8_t * g2 = c_grid_iq3xxs[q3[2 * l + 1]];
+                const uint32_t sg = c_signs_iq2[(aux >> (7 * l)) & 127];
+                for (int t = 0; t < 4; ++t) {
+                    sumi += (int) g1[t] * y[8 * l + t]     * (((sg >> t) & 1) ? -1 : 1);
+                    sumi += (int) g2[t] * y[8 * l + t + 4] * (((sg >> (t + 4)) & 1) ? -1 : 1);
+                }
+            }
+            return 0.25f * ((ld_h(w) * yd) * (float) (sumi * (2 * (int) (aux >> 28) + 1)));
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ3_S) {            // :11733-11776 block: d(2) qs[64] qh[8] signs[32] scales[4]
+            const uint8_t * w = wrow + b * 110; const uint8_t * qs = w + 2 + 8 * j; const int qh = w[66 + j]; const uint8_t * sg = w + 74 + 4 * j;
+            const int nib = (j & 1) ? (w[106 + (j >> 1)] >> 4) : (w[106 + (j >> 1)] & 0xf);
+            int sumi = 0;
+            for (int l = 0; l < 4; ++l) {
+                const uint8_t * g1 = c_grid_iq3s[qs[2 * l] | ((qh << (8 - 2 * l)) & 256)]; const uint8_t * g2 = c_grid_iq3s[qs[2 * l + 1] | ((qh << (7 - 2 * l)) & 256)];
+                for (int t = 0; t < 4; ++t) {
+                    sumi += (int) g1[t] * y[8 * l + t]     * (((sg[l] >> t) & 1) ? -1 : 1);
+                    sumi += (int) g2[t] * y[8 * l + t + 4] * (((sg[l] >> (t + 4)) & 1) ? -1 : 1);
+                }
+            }
+            return (ld_h(w) * yd) * (float) (sumi * (2 * nib + 1));
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ1_S) {            // :12099-12128 block: d(2) qs[32] qh u16[8]
+            const uint8_t * w = wrow + b * 50; const uint8_t * qs = w + 2 + 4 * j;
+            const uint32_t qh = (uint32_t) w[34 + 2 * j] | ((uint32_t) w[35 + 2 * j] << 8);
+            const int ls = 2 * (int) ((qh >> 12) & 7) + 1, delta = (qh & 0x8000) ? -1 : 1;
+            int lsum = 0;
+            for (int l = 0; l < 4; ++l) {
+                const int8_t * g = c_grid_iq1s[qs[l] | (((qh >> (3 * l)) & 7) << 8)];
+                for (int t = 0; t < 8; ++t) lsum += y[8 * l + t] * (int) g[t];
+            }
+            return ld_h(w) * yd * ((float) (ls * lsum) + 0.125f * (float) (ls * delta * (bs0 + bs1)));
+        } else if constexpr (TYPE == MI355Q_TYPE_IQ1_M) {            // :12401-12446 block: qs[32] qh[16] scales[8]
+            const uint8_t * w = wrow + b * 56; const uint8_t * qs = w + 4 * j; const uint8_t * qh = w + 32 + 2 * j;
+            uint32_t sc[4];
+            for (int t = 0; t < 4; ++t) sc[t] = (uint32_t) w[48 + 2 * t] | ((uint32_t) w[49 + 2 * t] << 8);
+            const uint32_t du = (sc[0] >> 12) | ((sc[1] >> 8) & 0x00f0u) | ((sc[2] >> 4) & 0x0f00u) | (sc[3] & 0xf000u);
+            const int delta[4] = { (qh[0] & 0x08) ? -1 : 1, (qh[0] & 0x80) ? -1 : 1, (qh[1] & 0x08) ? -1 : 1, (qh[1] & 0x80) ? -1 : 1 };
+            int sum1[2] = { 0, 0 }, sum2[2] = { 0, 0 };
+            for (int l = 0; l < 4; ++l) {
+                const int8_t * g = c_grid_iq1s[qs[l] | (((uint32_t) qh[l / 2] << (8 - 4 * (l % 2))) & 0x700)];
+                int l1 = 0, l2 = 0;
+                for (int t = 0; t < 8; ++t) { l1 += y[8 * l + t] * (int) g[t]; l2 += y[8 * l + t]; }
+                sum1[l / 2] += l1; sum2[l / 2] += l2 * delta[l];
+            }
+            const int ls1 = 2 * (int) ((sc[j / 2] >> (6 * (j % 2) + 0)) & 0x7) + 1, ls2 = 2 * (int) ((sc[j / 2] >> (6 * (j % 2) + 3)) & 0x7) + 1;
+            return h2f(du) * yd * ((float) (sum1[0] * ls1 + sum1[1] * ls2) + 0.125f * (float) (sum2[0] * ls1 + sum2[1] * ls2));
         } else {                                                     // IQ4_XS  :12981-13012
             const uint8_t * w = wrow + b * 136;
             const uint32_t sh = (uint32_t) w[2] | ((uint32_t) w[3] << 8);
@@ -182,6 +264,9 @@ int launch_gemv_generic(int type, const void * w, int64_t w_stride, const void *
         MI355Q_GENERIC_CASE(MI355Q_TYPE_Q3_K) MI355Q_GENERIC_CASE(MI355Q_TYPE_Q4_K)
         MI355Q_GENERIC_CASE(MI355Q_TYPE_Q5_K) MI355Q_GENERIC_CASE(MI355Q_TYPE_Q6_K)
         MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ4_NL) MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ4_XS)
+        MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ2_XXS) MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ2_XS) MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ2_S)
+        MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ3_XXS) MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ3_S)
+        MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ1_S) MI355Q_GENERIC_CASE(MI355Q_TYPE_IQ1_M)
     default: return MI355Q_ERR_UNSUPPORTED;
     }
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;

@@ -48,6 +48,14 @@ inline const TypeInfo * type_info(int type) {   // host only
         { MI355Q_TYPE_Q6_K,   256, 210, MI355Q_TYPE_Q8_K, 4, {{0, 128}, {128, 64}, {192, 16}, {208, 2}},  1 },
         { MI355Q_TYPE_IQ4_NL, 32,  18, MI355Q_TYPE_Q8_0, 2, {{2, 16}, {0, 2}, {0, 0}, {0, 0}},            0 },
         { MI355Q_TYPE_IQ4_XS, 256, 136, MI355Q_TYPE_Q8_K, 2, {{8, 128}, {0, 8}, {0, 0}, {0, 0}},          0 },
+        // code-book formats: canonical layout, generic tier (code books: iq_tables.h)
+        { MI355Q_TYPE_IQ2_XXS, 256, 66,  MI355Q_TYPE_Q8_K, 1, {{0, 66}, {0, 0}, {0, 0}, {0, 0}},          0 },
+        { MI355Q_TYPE_IQ2_XS,  256, 74,  MI355Q_TYPE_Q8_K, 1, {{0, 74}, {0, 0}, {0, 0}, {0, 0}},          0 },
+        { MI355Q_TYPE_IQ2_S,   256, 82,  MI355Q_TYPE_Q8_K, 1, {{0, 82}, {0, 0}, {0, 0}, {0, 0}},          0 },
+        { MI355Q_TYPE_IQ3_XXS, 256, 98,  MI355Q_TYPE_Q8_K, 1, {{0, 98}, {0, 0}, {0, 0}, {0, 0}},          0 },
+        { MI355Q_TYPE_IQ3_S,   256, 110, MI355Q_TYPE_Q8_K, 1, {{0, 110}, {0, 0}, {0, 0}, {0, 0}},         0 },
+        { MI355Q_TYPE_IQ1_S,   256, 50,  MI355Q_TYPE_Q8_K, 1, {{0, 50}, {0, 0}, {0, 0}, {0, 0}},          0 },
+        { MI355Q_TYPE_IQ1_M,   256, 56,  MI355Q_TYPE_Q8_K, 1, {{0, 56}, {0, 0}, {0, 0}, {0, 0}},          0 },
         // activation-only formats (never src0)
         { MI355Q_TYPE_Q8_1,   32,  36, -1, 0, {{0, 0}, {0, 0}, {0, 0}, {0, 0}},                            0 },
         { MI355Q_TYPE_Q8_K,   256, 292, -1, 0, {{0, 0}, {0, 0}, {0, 0}, {0, 0}},                           0 },

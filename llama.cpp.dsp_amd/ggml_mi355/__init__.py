@@ -29,11 +29,13 @@ LIB_PATH = Path(_os.environ["MI355Q_LIB"]) if _os.environ.get("MI355Q_LIB") else
 F32 = 0
 Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 2, 3, 6, 7, 8, 9
 Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K = 10, 11, 12, 13, 14, 15
-IQ4_NL, IQ4_XS = 20, 23
+IQ2_XXS, IQ2_XS, IQ3_XXS, IQ1_S, IQ4_NL, IQ3_S, IQ2_S, IQ4_XS, IQ1_M = 16, 17, 18, 19, 20, 21, 22, 23, 29
 TYPE_NAMES = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0", Q8_1: "q8_1",
               Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K",
-              IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs"}
-WEIGHT_TYPES = [Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ4_NL, IQ4_XS]
+              IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs", IQ2_XXS: "iq2_xxs", IQ2_XS: "iq2_xs", IQ2_S: "iq2_s", IQ3_XXS: "iq3_xxs",
+              IQ3_S: "iq3_s", IQ1_S: "iq1_s", IQ1_M: "iq1_m"}
+WEIGHT_TYPES = [Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ4_NL, IQ4_XS,
+                IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S, IQ1_S, IQ1_M]
 
 FLAG_ROUND_AWAY, FLAG_ROUND_EVEN = 0, 1
 

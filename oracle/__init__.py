@@ -29,6 +29,7 @@ TYPE_NAMES = {
     Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0", Q8_1: "q8_1",
     Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K",
     IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs",
+    IQ2_XXS: "iq2_xxs", IQ2_XS: "iq2_xs", IQ2_S: "iq2_s", IQ3_XXS: "iq3_xxs", IQ3_S: "iq3_s", IQ1_S: "iq1_s", IQ1_M: "iq1_m",
 }
 ROUND_AWAY, ROUND_EVEN = 0, 1
 

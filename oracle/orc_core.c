@@ -31,6 +31,13 @@ static const orc_geom k_geom[] = {
     { ORC_Q6_K,    256,  210,   ORC_Q8_K },
     { ORC_IQ4_NL,  32,   18,    ORC_Q8_0 },
     { ORC_IQ4_XS,  256,  136,   ORC_Q8_K },
+    { ORC_IQ2_XXS, 256,  66,    ORC_Q8_K },
+    { ORC_IQ2_XS,  256,  74,    ORC_Q8_K },
+    { ORC_IQ2_S,   256,  82,    ORC_Q8_K },
+    { ORC_IQ3_XXS, 256,  98,    ORC_Q8_K },
+    { ORC_IQ3_S,   256,  110,   ORC_Q8_K },
+    { ORC_IQ1_S,   256,  50,    ORC_Q8_K },
+    { ORC_IQ1_M,   256,  56,    ORC_Q8_K },
     /* activation-only formats */
     { ORC_Q8_1,    32,   36,    -1 },
     { ORC_Q8_K,    256,  292,   -1 },
@@ -99,6 +106,10 @@ uint16_t orc_f32_to_f16(float f) {
 }
 
 #define H2F(h) orc_f16_to_f32(h)
+
+/* code-book formats live in orc_iq.c */
+int orc_iq_dequantize_row(int type, const void *src, float *y, int64_t nb);
+int orc_iq_vec_dot(int type, int64_t nb, float *out, const void *vw, const void *va);
 
 /* ------------------------------------------------------------------------------------ */
 /* K-quant 6-bit (scale,min) pair j of the 12-byte field  (get_scale_min_k4,              */
@@ -258,7 +269,7 @@ int orc_dequantize_row(int type, const void *src, float *y, int64_t k) {
                     y[256 * i + 32 * ib + j]      = dl * (float) orc_iq4_codebook[x[i].qs[16 * ib + j] & 0x0F];
                     y[256 * i + 32 * ib + j + 16] = dl * (float) orc_iq4_codebook[x[i].qs[16 * ib + j] >> 4]; } } }
         return 0; }
-    default: return 2;
+    default: return orc_iq_dequantize_row(type, src, y, nb);
     }
 }
 
@@ -431,7 +442,7 @@ int orc_vec_dot(int type, int64_t k, float *out, const void *vw, const void *va)
                     s2 += y[i].qs[32 * ib + j + 16] * orc_iq4_codebook[x[i].qs[16 * ib + j] >> 4]; }
                 sumf += dl * (float)(s1 + s2); } }
         break; }
-    default: return 2;
+    default: return orc_iq_vec_dot(type, nb, out, vw, va);
     }
     *out = sumf;
     return 0;

@@ -35,7 +35,8 @@ def test_geometry_matches_oracle(G, orc):
         assert G.act_type(t) == orc.vec_dot_type(t)
         for k in (256, 4096, 14336):
             assert G.row_size(t, k) == orc.row_size(t, k)
-    assert G.lib().mi355q_type_supported(oracle.IQ2_XS) == 0
+    for other in (0, 1, 30, 34, 35):                  # f32, f16, bf16, tq1_0, tq2_0: not on this path
+        assert G.lib().mi355q_type_supported(other) == 0
     assert G.row_size(oracle.Q4_K, 100) == 0          # not a multiple of the block
 
 

@@ -23,7 +23,8 @@ from qdata import quantized_weights, random_blocks
 pytestmark = pytest.mark.gpu
 
 TYPES = [oracle.Q4_0, oracle.Q4_1, oracle.Q5_0, oracle.Q5_1, oracle.Q8_0, oracle.Q2_K, oracle.Q3_K,
-         oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.IQ4_NL, oracle.IQ4_XS]
+         oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.IQ4_NL, oracle.IQ4_XS,
+         oracle.IQ2_XXS, oracle.IQ2_XS, oracle.IQ2_S, oracle.IQ3_XXS, oracle.IQ3_S, oracle.IQ1_S, oracle.IQ1_M]
 FAST = [oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.Q8_0, oracle.Q4_0]
 ids_t = lambda t: oracle.TYPE_NAMES[t]
 

@@ -17,7 +17,7 @@ def _bits(a):
 
 
 def test_fixture_inventory():
-    assert len(MM) == 24 and len(MMID) == 24
+    assert len(MM) == 38 and len(MMID) == 38        # 19 weight types x 2 shapes each
 
 
 @pytest.mark.parametrize("path", MM, ids=lambda p: p.stem)

@@ -10,7 +10,8 @@ import oracle
 pytestmark = pytest.mark.skipif(not oracle.ref_available("scalar"), reason="oracle/_ref/scalar not built")
 
 TYPES = [oracle.Q4_0, oracle.Q4_1, oracle.Q5_0, oracle.Q5_1, oracle.Q8_0, oracle.Q2_K, oracle.Q3_K,
-         oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.IQ4_NL, oracle.IQ4_XS]
+         oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.IQ4_NL, oracle.IQ4_XS,
+         oracle.IQ2_XXS, oracle.IQ2_XS, oracle.IQ2_S, oracle.IQ3_XXS, oracle.IQ3_S, oracle.IQ1_S, oracle.IQ1_M]
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +62,11 @@ def test_random_block_bytes_decode(orc, ref, t):
     w = w.reshape(M, -1, bs); g = good.reshape(M, -1, bs)
     fields = {oracle.Q4_0: [(0, 2)], oracle.Q4_1: [(0, 4)], oracle.Q5_0: [(0, 2)], oracle.Q5_1: [(0, 4)],
               oracle.Q8_0: [(0, 2)], oracle.Q2_K: [(80, 84)], oracle.Q3_K: [(108, 110)], oracle.Q4_K: [(0, 4)],
-              oracle.Q5_K: [(0, 4)], oracle.Q6_K: [(208, 210)], oracle.IQ4_NL: [(0, 2)], oracle.IQ4_XS: [(0, 2)]}[t]
+              oracle.Q5_K: [(0, 4)], oracle.Q6_K: [(208, 210)], oracle.IQ4_NL: [(0, 2)], oracle.IQ4_XS: [(0, 2)]}.get(t, [(0, 2)])   # the IQ2/IQ3/IQ1_S blocks lead with d
+    if t == oracle.IQ1_M:        # f16 super-scale scattered over the top nibbles of scales[4] (u16 at 48..55)
+        for o in (49, 51, 53, 55):
+            w[:, :, o] = (w[:, :, o] & 0x0f) | (g[:, :, o] & 0xf0)
+        fields = []
     for a, b in fields:
         w[:, :, a:b] = g[:, :, a:b]
     w = w.reshape(M, rs)

@@ -69,7 +69,8 @@ def test_reference_test_backend_ops(op):
     print(f"{op}: {len(ran)} cases ran on MI355_0 and passed, {len(unsupported)} reported not supported")
     assert len(ran) + len(unsupported) == len(cases)
     assert len(ran) >= 150                      # the quantized cases really ran on the device
-    # every case of the 12 implemented weight types with f32 activations must have RUN (not been skipped)
-    for t in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_K", "q3_K", "q4_K", "q5_K", "q6_K", "iq4_nl", "iq4_xs"):
+    # every case of the 19 implemented weight types with f32 activations must have RUN (not been skipped)
+    for t in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_K", "q3_K", "q4_K", "q5_K", "q6_K", "iq4_nl", "iq4_xs",
+              "iq2_xxs", "iq2_xs", "iq2_s", "iq3_xxs", "iq3_s", "iq1_s", "iq1_m"):
         mine = [l for l in cases if f"type_a={t}," in l and "type_b=f32" in l]
         assert mine and all("OK" in l for l in mine if "per=[0,1,2,3]" in l and "v=0" in l), t
