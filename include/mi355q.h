@@ -172,6 +172,33 @@ int    mi355q_mul_mat_id(int type, const void *w, int64_t w_stride_bytes, int64_
                          float *y, int64_t m, int64_t k, int64_t n_used, int64_t n_tok,
                          void *workspace, size_t workspace_bytes, int flags, void *stream);
 
+/* ---- decode plan: a chain of N=1 MUL_MATs as ONE persistent launch --------------------------------------
+ * Replaces the reference's per-node launches + CUDA-graph replay of the token-generation graph
+ * (ggml-cuda.cu:2470-2781, evaluate_and_capture_cuda_graph / ggml_backend_cuda_graph_compute) for the
+ * MUL_MAT nodes of a decode step.  A STAGE is 1..4 weight matrices (planar device rows, types may differ)
+ * against one f32 activation vector x[k]; y_i[m_i] = W_i . x exactly as mi355q_mul_mat computes it
+ * (bit-identical).  Stages run in order inside one cooperative launch; the weight stream continues across
+ * stage boundaries.  MI355Q_STAGE_DEPENDS: x of this stage is written (directly, or by another agent on the
+ * same device before it is read) from results of EARLIER stages of the same run -> a grid-wide barrier
+ * orders it.  Without the flag x must be complete before the launch.
+ * Only types with a planar layout at this k (mi355q_weights_are_planar) are accepted.
+ * run(): asynchronous on `stream`.  status(): synchronizes; 1 = a barrier timed out (plan unusable). */
+#define MI355Q_STAGE_DEPENDS 0x1
+typedef struct mi355q_stage {
+    mi355q_mat   mats[4];    /* y_stride is unused (one activation row) */
+    int          n_mats;
+    int          flags;
+    const float *x;          /* device, k floats */
+    int64_t      k;
+} mi355q_stage;
+typedef struct mi355q_plan mi355q_plan;
+int     mi355q_plan_create(mi355q_plan **out, const mi355q_stage *stages, int n_stages, int flags);
+int     mi355q_plan_run(mi355q_plan *plan, void *stream);
+int     mi355q_plan_status(mi355q_plan *plan);
+int64_t mi355q_plan_weight_bytes(const mi355q_plan *plan);
+int     mi355q_plan_launch_stages(const mi355q_plan *plan);
+int     mi355q_plan_destroy(mi355q_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

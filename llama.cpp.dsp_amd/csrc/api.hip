@@ -57,6 +57,7 @@ extern "C" {
 
 int mi355q_api_version(void) { return MI355Q_API_VERSION; }
 const char * mi355q_last_error(void) { return t_err; }
+__attribute__((visibility("hidden"))) void mi355q_set_error(const char * msg) { fail(0, "%s", msg); }   // for the other translation units
 
 int mi355q_device_count(void) {
     int n = 0;

@@ -50,6 +50,8 @@ ABI_SYMBOLS = [
     "mi355q_quantize_act",
     "mi355q_mul_mat_workspace", "mi355q_mul_mat", "mi355q_mul_mat_multi",
     "mi355q_mul_mat_id_workspace", "mi355q_mul_mat_id",
+    "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
+    "mi355q_plan_destroy",
 ]
 
 
@@ -61,6 +63,12 @@ class _Mat(C.Structure):
     _fields_ = [("type", C.c_int), ("w", C.c_void_p), ("w_stride", C.c_int64), ("y", C.c_void_p),
                 ("y_stride", C.c_int64), ("m", C.c_int64)]
 
+
+class _Stage(C.Structure):
+    _fields_ = [("mats", _Mat * 4), ("n_mats", C.c_int), ("flags", C.c_int), ("x", C.c_void_p), ("k", C.c_int64)]
+
+
+STAGE_DEPENDS = 0x1
 
 _lib = None
 
@@ -91,6 +99,12 @@ def lib() -> C.CDLL:
     L.mi355q_mul_mat_workspace.restype = sz; L.mi355q_mul_mat_workspace.argtypes = [i32, i64, i64, i64]
     L.mi355q_mul_mat.argtypes = [i32, vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     L.mi355q_mul_mat_multi.argtypes = [C.POINTER(_Mat), i32, vp, i64, i64, i64, vp, sz, i32, vp]
+    L.mi355q_plan_create.argtypes = [C.POINTER(vp), C.POINTER(_Stage), i32, i32]
+    L.mi355q_plan_run.argtypes = [vp, vp]
+    L.mi355q_plan_status.argtypes = [vp]
+    L.mi355q_plan_destroy.argtypes = [vp]
+    L.mi355q_plan_weight_bytes.restype = i64; L.mi355q_plan_weight_bytes.argtypes = [vp]
+    L.mi355q_plan_launch_stages.argtypes = [vp]
     L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64]
     L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     _lib = L
@@ -211,6 +225,58 @@ def mul_mat_multi(ws_: list, x, outs=None, flags: int = 0):
     _check(lib().mi355q_mul_mat_multi(arr, len(ws_), x.data_ptr(), x.stride(0) * 4, n, k,
                                       ws.data_ptr() if ws is not None else None, wsb, flags, _stream(torch)), "mul_mat_multi")
     return ys
+
+
+class Plan:
+    """A chain of N=1 MUL_MATs as ONE persistent launch (mi355q_plan_*).
+
+    stages: list of (weights: list[QWeight] (<= 4, same K), x: f32 [1, K] or [K], ys: list of f32 [1, M_i] / [M_i],
+                     depends: bool -- x is produced from earlier stages' outputs during the run).
+    The tensors are referenced by address: keep them alive (the Plan holds references) and do not move them."""
+
+    def __init__(self, stages, flags: int = 0):
+        torch = _torch()
+        arr = (_Stage * len(stages))()
+        self._keep = []
+        for i, (ws_, x, ys, depends) in enumerate(stages):
+            k = x.shape[-1]
+            assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == k
+            assert 1 <= len(ws_) <= 4 and len(ws_) == len(ys)
+            st = _Stage()
+            for j, (w, y) in enumerate(zip(ws_, ys)):
+                assert w.K == k and w.n_expert == 1 and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == w.M
+                st.mats[j] = _Mat(w.type, w.data.data_ptr(), w.row_bytes, y.data_ptr(), w.M * 4, w.M)
+            st.n_mats = len(ws_); st.flags = STAGE_DEPENDS if depends else 0; st.x = x.data_ptr(); st.k = k
+            arr[i] = st
+            self._keep.append((ws_, x, ys))
+        h = C.c_void_p()
+        _check(lib().mi355q_plan_create(C.byref(h), arr, len(stages), flags), "plan_create")
+        self._h = h
+
+    @property
+    def weight_bytes(self) -> int:
+        return int(lib().mi355q_plan_weight_bytes(self._h))
+
+    @property
+    def launch_stages(self) -> int:
+        return int(lib().mi355q_plan_launch_stages(self._h))
+
+    def run(self):
+        _check(lib().mi355q_plan_run(self._h, _stream(_torch())), "plan_run")
+
+    def status(self) -> int:
+        return int(lib().mi355q_plan_status(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mi355q_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def mul_mat_id(w: QWeight, x, ids, flags: int = 0):
