@@ -3,10 +3,13 @@
 
 One "step" = one generated token = one pass over every quantized matmul weight the token touches
 (32 x {attn_q, attn_k, attn_v, attn_output, ffn_gate, ffn_up, ffn_down} + output: 225 matrices, 4.616 GB,
-BASELINE.md section 3), N=1 activation column, issued the way the backend issues them: 4 launches per layer
-(q/k/v fused, attn_output, gate/up fused, ffn_down) + 1, captured in a hipGraph.  Inputs (weights and
-activations) are resident in HBM before the timed region.  Non-matmul graph ops (norm, rope, attention,
-softmax...) are NOT part of this path and are not executed (they are the "next" rows).
+BASELINE.md section 3), N=1 activation column, in 4 dependent steps per layer (q/k/v fused, attn_output, gate/up
+fused, ffn_down) + 1.  Default (--launch plan): the whole token is ONE persistent cooperative launch
+(mi355q_plan_*: grid barriers between the dependent steps, weights prefetched across them); --launch graph:
+one launch per step (129), captured in a hipGraph.  Inputs (weights and activations) are resident in HBM before the
+timed region.  Non-matmul graph ops (norm, rope, attention, softmax...) are NOT part of this path and are not
+executed (they are the "next" rows): every step after the first is ordered behind the previous
+one exactly as the real graph orders them, but reads a pre-filled activation buffer.
 
   python bench.py [--gpus N --steps K --warmup W]         (N>1: launched by torch.distributed.run)
 
@@ -39,7 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=128)     # tg128
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--ftype", default="Q4_K_M", choices=["Q4_K_M", "Q8_0"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--launch", default="plan", choices=["plan", "graph", "eager"],
+                    help="plan: one persistent launch per token (default); graph: 129 launches in a hipGraph; eager: 129 plain launches")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--no-fuse", action="store_true", help="one launch per matrix (no q/k/v, gate/up fusion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
@@ -93,6 +98,10 @@ class Stage:
                 nbytes = sum(w.nbytes for w in ws)
                 self.groups.append((ws, x_for(ws[0].K), ys, nbytes))
                 self.bytes += nbytes
+
+    def make_plan(self):
+        """The same steps as ONE persistent launch; every step after the first waits (grid barrier) for the previous one."""
+        return self.g.Plan([(ws, x, ys, i > 0) for i, (ws, x, ys, _) in enumerate(self.groups)])
 
     def run(self):
         g = self.g
@@ -186,16 +195,32 @@ def main():
                 dist.send(act, dst=rank + 1)
     else:
         stage = Stage(torch, g, mine, not a.no_fuse, device)
-        graph = None
-        if not a.no_graph:
-            stage.run(); torch.cuda.synchronize()              # warm every kernel / attribute before capture
+        launch = "eager" if a.no_graph else a.launch
+        graph = plan = None
+        stage.run(); torch.cuda.synchronize()                  # warm every kernel / attribute (and the reference outputs for the plan check)
+        if launch == "graph":
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 stage.run()
+        elif launch == "plan":
+            want = [[y.clone() for y in ys] for _, _, ys, _ in stage.groups]
+            plan = stage.make_plan()
+            for _, _, ys, _ in stage.groups:
+                for y in ys:
+                    y.zero_()
+            plan.run(); torch.cuda.synchronize()
+            if plan.status() != 0:
+                raise RuntimeError("decode plan aborted (grid barrier timeout)")
+            for (_, _, ys, _), ws_ in zip(stage.groups, want):  # the persistent launch computes exactly what the per-matmul launches do
+                for y, w_ in zip(ys, ws_):
+                    if not torch.equal(y.view(torch.int32), w_.view(torch.int32)):
+                        raise RuntimeError("decode plan output differs from the per-matmul launches")
+            del want
+        run_token = plan.run if plan is not None else (graph.replay if graph is not None else stage.run)
         def token():
             if world > 1 and rank > 0:
                 dist.recv(act, src=rank - 1)                    # boundary activation from the previous stage
-            graph.replay() if graph is not None else stage.run()
+            run_token()
             if world > 1 and rank < world - 1:
                 dist.send(act, dst=rank + 1)
 
@@ -227,23 +252,30 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "int8",
         "data": "synthetic (random packed blocks with finite scales, gaussian activations)",
         "config": {"workload": f"Llama-3-8B {a.ftype} tg (N=1): all {len(specs)} quantized mul_mat weights per token, "
-                               f"{total_bytes / 1e9:.3f} GB/token; {'fused q|k|v and gate|up launches, ' if not a.no_fuse else ''}"
-                               f"{'hipGraph replay' if not a.no_graph else 'eager launches'}; non-matmul graph ops not executed",
+                               f"{total_bytes / 1e9:.3f} GB/token; {'fused q|k|v and gate|up steps, ' if not a.no_fuse else ''}"
+                               + {"plan": "one persistent cooperative launch per token (grid barrier between dependent steps)",
+                                  "graph": "one launch per step, hipGraph replay", "eager": "one launch per step, eager"}["eager" if a.no_graph else a.launch]
+                               + "; non-matmul graph ops not executed",
                    "bytes_per_token": total_bytes,
                    "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs (RCCL send/recv of the boundary activation)"},
     }
 
     if not a.dry_run and rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ----
-        # Every launch of the token is the same kernel template (k_gemv_fast); its instantiations are timed per
-        # (weight type, K) class: the launches of a class are captured back to back in their own hipGraph and the
-        # replay is bracketed by HIP events on the stream it runs on.  avg duration = event time / launches
-        # (includes the ~1.5 us kernel boundary; rocprofv3's kernel-only average under profiles/ is that much lower).
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def timed(fn, reps):
+            fn(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+        # (a) the per-matmul launch path: every launch is the same kernel template (k_gemv_fast); its instantiations are timed
+        # per (weight type, K) class, the launches of a class captured back to back in their own hipGraph.
         classes = {}
         for ws, x, ys, nbytes in stage.groups:
             classes.setdefault((g.TYPE_NAMES[ws[0].type], ws[0].K), []).append((ws, x, ys, nbytes))
         per_kernel = {}
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for (tname, kk), grp in classes.items():
             def run_class():
                 for ws, x, ys, _ in grp:
@@ -253,17 +285,22 @@ def main():
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
                 run_class()
-            cg.replay(); torch.cuda.synchronize()
-            reps = 20
-            e0.record()
-            for _ in range(reps):
-                cg.replay()
-            e1.record(); torch.cuda.synchronize()
-            secs = e0.elapsed_time(e1) * 1e-3 / reps
+            secs = timed(cg.replay, 20)
             nb = sum(t[3] for t in grp)
             per_kernel[f"k_gemv_fast<{tname}, K={kk}, N=1>"] = {"launches_per_token": len(grp), "bytes_per_token": nb, "avg_launch_us": round(1e6 * secs / len(grp), 2),
                                                                 "algorithmic_bytes_per_launch": nb // len(grp), "GBps": round(nb / secs / 1e9, 1)}
-        dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["bytes_per_token"])
+        if plan is not None:
+            # (b) the persistent launch IS the token: one kernel, algorithmic bytes = every weight byte of this rank's layers
+            secs = timed(plan.run, 20)
+            if plan.status() != 0:
+                raise RuntimeError("decode plan aborted (grid barrier timeout)")
+            dom_name = "k_plan (persistent decode plan, %d steps)" % plan.launch_stages
+            dom = {"launches_per_token": 1, "bytes_per_token": stage.bytes, "avg_launch_us": round(1e6 * secs, 2),
+                   "algorithmic_bytes_per_launch": stage.bytes, "GBps": round(stage.bytes / secs / 1e9, 1)}
+            all_kernels = {dom_name: dom, "per_matmul_launch_path_for_comparison": per_kernel}
+        else:
+            dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["bytes_per_token"])
+            all_kernels = per_kernel
         achieved = dom["GBps"]
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -271,7 +308,7 @@ def main():
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
                            "whole_token_GBps": round(total_bytes * a.steps / dt / 1e9, 1) if world == 1 else None,
                            "measured_hbm_read_peak_GBps": measured_hbm_read_GBps(torch, device),   # this box, plain streaming read (guide: ~6.3 TB/s)
-                           "all_kernels": per_kernel}
+                           "all_kernels": all_kernels}
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(specs, a.cpu_seconds)

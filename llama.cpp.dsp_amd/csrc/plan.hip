@@ -11,9 +11,10 @@
 //     the barrier and the activation quantization.  (A per-matmul launch pays kernel boundary +
 //     dispatch + ring prime + quantize prologue serially, ~5-8 us)
 //   * the dependency between stages (y of one feeds, through the graph's glue ops, x of the next) is a
-//     grid barrier: a monotonic arrive counter in device memory, one relaxed agent-scope atomic per
-//     workgroup, polled by one lane.  Outputs are written with agent-scope (sc1, write-through) stores and
-//     acknowledged (vmcnt) before the arrival; activations are read with sc1 loads, so no cache
+//     grid barrier in device memory: two-level arrive counters (no cache line is touched by more than
+//     ~32 workgroups: one counter hammered by 256 pollers costs 5-20 us per barrier on this chip), relaxed
+//     agent-scope atomics, polled by one wave.  Outputs are written with agent-scope (sc1, write-through)
+//     stores and acknowledged (vmcnt) before the arrival; activations are read with sc1 loads, so no cache
 //     invalidate / write-back fences (which would also drain the in-flight weight loads) are needed.
 //   * a stage that reuses the previous stage's x (Q4_K wq|wk followed by Q6_K wv of a Q4_K_M layer)
 //     needs neither barrier nor re-quantization: the LDS image stays.
@@ -45,14 +46,16 @@ constexpr int PLAN_GROUPS = 8, PLAN_LINE = 32;
 enum { PLAN_SYNC_ARRIVE = 0, PLAN_SYNC_RELEASE = PLAN_GROUPS * PLAN_LINE, PLAN_SYNC_EXIT = 2 * PLAN_GROUPS * PLAN_LINE,
        PLAN_SYNC_ABORT = PLAN_SYNC_EXIT + PLAN_LINE, PLAN_SYNC_WORDS = PLAN_SYNC_ABORT + PLAN_LINE };
 
-struct alignas(16) PlanStage {
+struct alignas(64) PlanStage {
+    // -- what the streamers need per row, contiguous (arrives with a few scalar loads issued together) --
     const uint8_t * w[GEMV_MAX_MATS];
-    float *         y[GEMV_MAX_MATS];
     int64_t         w_stride[GEMV_MAX_MATS];
-    int             row_begin[GEMV_MAX_MATS];     // first concatenated row of each matrix
+    float *         y[GEMV_MAX_MATS];
+    int             row_begin[GEMV_MAX_MATS];     // first concatenated row of each matrix (unused entries: INT_MAX)
+    int             total_rows, rows_per_wg, k, n_mats;
+    // -- the rest --
     const float *   x;
-    int             total_rows, rows_per_wg, n_mats, type;
-    int             k, flags, x_vec, prime;       // prime: ring slots requested before the barrier / quantization
+    int             type, flags, prime, pad;      // prime: ring slots requested before the barrier / quantization
 };
 typedef const __attribute__((address_space(4))) PlanStage * StageC;   // descriptors are read with scalar loads
 
@@ -78,20 +81,37 @@ __device__ int g_plan_stamp_stages = 0;
 
 __device__ __forceinline__ bool plan_type_is_q8k(int t) { return t == MI355Q_TYPE_Q4_K || t == MI355Q_TYPE_Q5_K || t == MI355Q_TYPE_Q6_K; }
 
-__device__ __forceinline__ int plan_mat_of_row(StageC st, int gr) {
-    int mi = 0;
-#pragma unroll
-    for (int j = 1; j < GEMV_MAX_MATS; ++j) if (j < st->n_mats && gr >= st->row_begin[j]) mi = j;
-    return mi;
-}
-__device__ __forceinline__ const uint8_t * plan_row_ptr(StageC st, int gr) {
-    const int mi = plan_mat_of_row(st, gr);
-    return st->w[mi] + (int64_t) (gr - st->row_begin[mi]) * st->w_stride[mi];
-}
-__device__ __forceinline__ float * plan_y_ptr(StageC st, int gr) {
-    const int mi = plan_mat_of_row(st, gr);
-    return st->y[mi] + (gr - st->row_begin[mi]);
-}
+// A wave's own copy of the per-matrix fields of a stage descriptor, in SGPRs: read once per stage with independent
+// scalar loads (one round trip).  Reading them per row instead (matrix index -> base -> stride: a dependent chain of
+// scalar loads) costs microseconds whenever the descriptors miss the scalar cache.
+struct StageW {
+    const uint8_t * w0, * w1, * w2, * w3; int64_t ws0, ws1, ws2, ws3; float * y0, * y1, * y2, * y3; int rb1, rb2, rb3;
+    __device__ __forceinline__ void load(StageC st) {
+        w0 = st->w[0]; w1 = st->w[1]; w2 = st->w[2]; w3 = st->w[3];
+        ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = st->w_stride[2]; ws3 = st->w_stride[3];
+        y0 = st->y[0]; y1 = st->y[1]; y2 = st->y[2]; y3 = st->y[3];
+        rb1 = st->row_begin[1]; rb2 = st->row_begin[2]; rb3 = st->row_begin[3];
+    }
+    // all fields are read BEFORE the selects (a select between field addresses would keep the struct in scratch memory)
+    __device__ __forceinline__ const uint8_t * row_ptr(int r) const {
+        const uint64_t a0 = (uint64_t) w0, a1 = (uint64_t) w1, a2 = (uint64_t) w2, a3 = (uint64_t) w3;
+        const int64_t s0 = ws0, s1 = ws1, s2 = ws2, s3 = ws3;
+        const int b1 = rb1, b2 = rb2, b3 = rb3;
+        const int mi = (r >= b1) + (r >= b2) + (r >= b3);      // row_begin is ascending
+        const uint64_t w = mi == 0 ? a0 : mi == 1 ? a1 : mi == 2 ? a2 : a3;
+        const int64_t ws = mi == 0 ? s0 : mi == 1 ? s1 : mi == 2 ? s2 : s3;
+        const int rb = mi == 0 ? 0 : mi == 1 ? b1 : mi == 2 ? b2 : b3;
+        return (const uint8_t *) (w + (uint64_t) ((int64_t) (r - rb) * ws));
+    }
+    __device__ __forceinline__ float * y_ptr(int r) const {
+        const uint64_t a0 = (uint64_t) y0, a1 = (uint64_t) y1, a2 = (uint64_t) y2, a3 = (uint64_t) y3;
+        const int b1 = rb1, b2 = rb2, b3 = rb3;
+        const int mi = (r >= b1) + (r >= b2) + (r >= b3);
+        const uint64_t y = mi == 0 ? a0 : mi == 1 ? a1 : mi == 2 ? a2 : a3;
+        const int rb = mi == 0 ? 0 : mi == 1 ? b1 : mi == 2 ? b2 : b3;
+        return (float *) y + (r - rb);
+    }
+};
 
 struct StageGeom { int r_hi, nb, nchunks, steps; };
 template <int T> __device__ __forceinline__ StageGeom plan_geom(int k, int r_hi) {
@@ -103,23 +123,23 @@ template <int T> __device__ __forceinline__ StageGeom plan_geom(int k, int r_hi)
 }
 
 template <int T>
-__device__ __forceinline__ void plan_issue(Chunk & slot, PlanCursor & ld, StageC st, const StageGeom & g, int lane) {
+__device__ __forceinline__ void plan_issue(Chunk & slot, PlanCursor & ld, const StageW & st, const StageGeom & g, int lane) {
     if (ld.gr < g.r_hi) {                                     // wave-uniform
         if (64 * ld.s + lane < g.nchunks) chunk_load<T>(slot, ld.row, g.nb, ld.s, lane);
-        if (++ld.s == g.steps) { ld.s = 0; ld.gr += GEMV_WAVES; if (ld.gr < g.r_hi) ld.row = plan_row_ptr(st, ld.gr); }
+        if (++ld.s == g.steps) { ld.s = 0; ld.gr += GEMV_WAVES; if (ld.gr < g.r_hi) ld.row = st.row_ptr(ld.gr); }
     }
 }
 
 // request slots [from, to) of the ring for stage st (its loader cursor continues where it stands)
 template <int T, int D>
-__device__ __forceinline__ void plan_fill(Chunk (&ring)[D], int from, int to, PlanCursor & ld, StageC st, const StageGeom & g, int lane) {
+__device__ __forceinline__ void plan_fill(Chunk (&ring)[D], int from, int to, PlanCursor & ld, const StageW & st, const StageGeom & g, int lane) {
 #pragma unroll
     for (int d = 0; d < D; ++d) if (d >= from && d < to) plan_issue<T>(ring[d], ld, st, g, lane);
 }
 
 // consume this wave's rows of the stage; slot d holds item d, d+D, ... ; refills keep D items in flight
 template <int T, int D>
-__device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, StageC st, const StageGeom & g, int r_lo, int wave, int lane, const ActView * av) {
+__device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, const StageW & st, const StageGeom & g, int r_lo, int wave, int lane, const ActView * av) {
     // the consumers' lane-invariant state (LDS offsets, shifts) is derived from an opaque copy of the lane id HERE, so
     // that it cannot be computed (and kept live, and spilled) before the barrier / quantization phase
     int lane_c = lane; asm volatile("" : "+v"(lane_c));
@@ -132,7 +152,7 @@ __device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, Stag
                 if (64 * cs_s + lane_c < g.nchunks) Consume<T, 1>::run(ring[d], cs_s, lane_c, av, acc);
                 if (++cs_s == g.steps) {                      // row finished: reduce, store (agent-coherent), next row
                     const float t = wave_sum(acc[0]);
-                    if (lane_c == 0) __hip_atomic_store(plan_y_ptr(st, cs_gr), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane_c == 0) __hip_atomic_store(st.y_ptr(cs_gr), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     acc[0] = 0.0f; cs_s = 0; cs_gr += GEMV_WAVES;
                 }
                 plan_issue<T>(ring[d], ld, st, g, lane);      // refill the slot just consumed
@@ -153,8 +173,7 @@ __device__ __forceinline__ float4 plan_act_fetch(__amdgpu_buffer_rsrc_t xr, int 
 // LDS visibility + workgroup barrier WITHOUT draining vmcnt: __syncthreads() fences every address space and so waits
 // for the weight loads in flight; these fences name the LDS only (lgkmcnt), and -- unlike a bare s_barrier, which is
 // IntrNoMem for the compiler -- they also keep the LDS accesses on their side of the barrier at compile time.
-__device__ __forceinline__ void plan_lds_barrier(int dbg = 0) {
-    if (dbg & 1) { __syncthreads(); return; }
+__device__ __forceinline__ void plan_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -170,10 +189,10 @@ __device__ __forceinline__ void plan_quantize_span(const float4 v, int span, uin
 
 // Called by wave 0 (all 64 lanes) of a workgroup: wait until every workgroup has arrived `arrivals` times.
 // false on timeout / abort.
-__device__ __forceinline__ bool plan_grid_wait(unsigned * sync, unsigned arrivals, unsigned grid, unsigned long long timeout_ticks, int lane, bool flat) {
+__device__ __forceinline__ bool plan_grid_wait(unsigned * sync, unsigned arrivals, unsigned grid, unsigned long long timeout_ticks, int lane) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned g = blockIdx.x % PLAN_GROUPS;
-    const bool leader = flat || blockIdx.x < PLAN_GROUPS;
+    const bool leader = blockIdx.x < PLAN_GROUPS;
     // leader: lane l < 8 watches group l (target = arrivals * size of group l); follower: lane 0 watches release[g]
     const unsigned l = (unsigned) lane < (unsigned) PLAN_GROUPS ? (unsigned) lane : 0u;
     const unsigned gsize = grid > l ? (grid - l + PLAN_GROUPS - 1) / PLAN_GROUPS : 0u;
@@ -197,7 +216,7 @@ __device__ __forceinline__ bool plan_grid_wait(unsigned * sync, unsigned arrival
         }
         __builtin_amdgcn_s_sleep(2);
     }
-    if (leader && !flat && lane == 0) __hip_atomic_store(sync + PLAN_SYNC_RELEASE + g * PLAN_LINE, arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (leader && lane == 0) __hip_atomic_store(sync + PLAN_SYNC_RELEASE + g * PLAN_LINE, arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
@@ -206,7 +225,7 @@ __device__ __forceinline__ bool plan_grid_wait(unsigned * sync, unsigned arrival
 //   prime (weights in flight) -> [grid barrier] -> [quantize x -> LDS] -> stream rows -> [acknowledge y, arrive]
 struct StageCtx {
     uint8_t * lds; uint8_t * stage_lds; int * ctl; unsigned * sync; unsigned long long timeout;
-    unsigned grid, arrivals; int even, next_barrier, dbg, stage;
+    unsigned grid, arrivals; int even, next_barrier, stage;
 };
 enum { CTL_OK = 0, CTL_WAVES = 1 };
 
@@ -225,26 +244,26 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     Chunk ring[PLAN_D];
     PlanCursor ld;
     ld.gr = r_lo + wave; ld.s = 0; ld.row = nullptr;
-    if (ld.gr < r_hi) ld.row = plan_row_ptr(st, ld.gr);
+    StageW sw; sw.load(st);
+    if (ld.gr < r_hi) ld.row = sw.row_ptr(ld.gr);
     PLAN_STAMP(0);
-    plan_fill<T, PLAN_D>(ring, 0, st->prime, ld, st, g, lane);                 // weights start flowing before anything else
+    plan_fill<T, PLAN_D>(ring, 0, st->prime, ld, sw, g, lane);                 // weights start flowing before anything else
     PLAN_STAMP(1);
 
     if (flags & PLAN_F_BARRIER) {                             // every workgroup has finished (and made visible) all earlier stages
         if (wave == 0) {
-            const bool ok = plan_grid_wait(c.sync, c.arrivals, c.grid, c.timeout, lane, (c.dbg & 8) != 0);
+            const bool ok = plan_grid_wait(c.sync, c.arrivals, c.grid, c.timeout, lane);
             if (lane == 0) c.ctl[CTL_OK] = ok ? 1 : 0;
         }
-        plan_lds_barrier(c.dbg);
+        plan_lds_barrier();
         if (!c.ctl[CTL_OK]) return false;
     } else if (flags & PLAN_F_NEW_X) {
-        plan_lds_barrier(c.dbg);                                   // all waves are done with the previous LDS image
+        plan_lds_barrier();                                   // all waves are done with the previous LDS image
     }
     PLAN_STAMP(2);
     if (flags & PLAN_F_NEW_X) {
-        // Spans of 256 activations are dealt round-robin to the waves, four per pass.  Order matters (the CU's memory
-        // pipeline is a FIFO): the activation loads go out first, THEN the ring is topped up, so the weights stream
-        // while the activations are waited for and quantized.
+        // Spans of 256 activations are dealt round-robin to the waves, four in flight per wave (one memory round trip for
+        // k <= 16384).  Agent-scope (sc1) buffer loads: another XCD wrote them during this launch; lanes beyond k read 0.
         constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? FAM_Q80 : FAM_Q8K;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) st->x, 0, k * 4, 0x00020000);
         const int spans = (k + 255) >> 8;
@@ -271,13 +290,13 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
             stg[0] = x0; stg[64] = x1; stg[128] = x2; stg[192] = x3;
             quantize4(span);
         }
-        plan_lds_barrier(c.dbg);
+        plan_lds_barrier();
     }
-    plan_fill<T, PLAN_D>(ring, st->prime, PLAN_D, ld, st, g, lane);                // top the ring up (a no-op when prime == depth)
+    plan_fill<T, PLAN_D>(ring, st->prime, PLAN_D, ld, sw, g, lane);                // top the ring up (a no-op when prime == depth)
     PLAN_STAMP(3);
     ActView av[1];
     av[0].base = c.lds; av[0].k = k;
-    plan_run<T, PLAN_D>(ring, ld, st, g, r_lo, wave, lane, av);
+    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av);
     PLAN_STAMP(4);
 
     if (c.next_barrier) {
@@ -294,16 +313,16 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
 
 template <unsigned SET>
 __global__ void __launch_bounds__(GEMV_THREADS)
-k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsigned long long timeout_ticks, int lds_image_bytes, int dbg) {
+k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsigned long long timeout_ticks, int lds_image_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     StageC stages = (StageC) stages_g;
     if (__hip_atomic_load(sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // sticky: a plan that timed out stays dead
 
     StageCtx c;
     c.lds = lds; c.ctl = (int *) (lds + lds_image_bytes); c.stage_lds = lds + lds_image_bytes + 64; c.sync = sync; c.timeout = timeout_ticks;
-    c.grid = gridDim.x; c.arrivals = 0; c.even = even; c.dbg = dbg;
+    c.grid = gridDim.x; c.arrivals = 0; c.even = even;
     if (threadIdx.x == 0) { c.ctl[CTL_OK] = 1; c.ctl[CTL_WAVES] = 0; }
-    plan_lds_barrier(c.dbg);
+    plan_lds_barrier();
 
 #pragma unroll 1
     for (int s = 0; s < n_stages; ++s) {
@@ -386,7 +405,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
     unsigned set = 0; size_t lds_max = 0; int64_t bytes = 0;
     for (int s = 0; s < n_stages; ++s) {
         const mi355q_stage & in = stages[s];
-        if (in.n_mats < 1 || in.n_mats > GEMV_MAX_MATS || !in.x || in.k <= 0) { mi355q_set_error("plan_create: bad stage"); return MI355Q_ERR_SHAPE; }
+        if (in.n_mats < 1 || in.n_mats > GEMV_MAX_MATS || !in.x || in.k <= 0 || ((uintptr_t) in.x & 3)) { mi355q_set_error("plan_create: bad stage"); return MI355Q_ERR_SHAPE; }
         bool done[GEMV_MAX_MATS] = { false, false, false, false };
         bool first = true;
         for (int i = 0; i < in.n_mats; ++i) {
@@ -409,7 +428,6 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             if (rows > 0x7FFFFFF0) { mi355q_set_error("plan_create: too many rows"); return MI355Q_ERR_UNSUPPORTED; }
             for (int j = n; j < GEMV_MAX_MATS; ++j) p.row_begin[j] = 0x7FFFFFFF;
             p.x = in.x; p.total_rows = (int) rows; p.n_mats = n; p.type = type; p.k = (int) in.k;
-            p.x_vec = (((uintptr_t) in.x) & 15) == 0 ? 1 : 0;
             // barrier + fresh activations at the head of a dependent stage; same-x continuation otherwise
             const bool depends = (in.flags & MI355Q_STAGE_DEPENDS) && !v.empty();
             const bool reuse = !first || (!depends && !v.empty() && v.back().x == in.x && v.back().k == (int) in.k &&
@@ -418,7 +436,6 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;
             p.prime = plan_depth(type);
-            if (const char * e = getenv("MI355Q_PLAN_PRIME")) { if (p.flags & PLAN_F_BARRIER) { p.prime = atoi(e); if (p.prime < 0) p.prime = 0; if (p.prime > plan_depth(type)) p.prime = plan_depth(type); } }
             v.push_back(p);
             set |= tbit(type);
             const size_t colb = ((size_t) lds_col_bytes(fam, (int) in.k) + 15) & ~(size_t) 15;
@@ -455,10 +472,9 @@ int mi355q_plan_run(mi355q_plan * plan, void * stream) {
     if (!pl) { mi355q_set_error("plan_run: null plan"); return MI355Q_ERR_SHAPE; }
     const PlanStage * st = pl->d_stages; int n = pl->n_stages; unsigned * sync = pl->d_sync; int even = pl->even;
     int image = (int) pl->lds_bytes;
-    int dbg = getenv("MI355Q_PLAN_DBG") ? atoi(getenv("MI355Q_PLAN_DBG")) : 0;
     unsigned long long timeout = 100ull * 1000 * 20;          // 20 ms of the 100 MHz real-time counter per barrier
     if (const char * e = getenv("MI355Q_PLAN_TIMEOUT_MS")) timeout = 100ull * 1000 * (unsigned long long) atoll(e);
-    void * args[] = { (void *) &st, (void *) &n, (void *) &sync, (void *) &even, (void *) &timeout, (void *) &image, (void *) &dbg };
+    void * args[] = { (void *) &st, (void *) &n, (void *) &sync, (void *) &even, (void *) &timeout, (void *) &image };
     const hipError_t rc = hipLaunchCooperativeKernel(plan_kernel(pl->set), dim3((unsigned) pl->grid), dim3(GEMV_THREADS), args,
                                                      pl->lds_bytes + 64 + GEMV_WAVES * 4096, (hipStream_t) stream);
     if (rc != hipSuccess) { mi355q_set_error(hipGetErrorString(rc)); return MI355Q_ERR_HIP; }

@@ -369,3 +369,79 @@ def test_output_layer_rows(G, torch, orc):
     assert np.array_equal(y[0, M - 4096 + (4096 - M % 4096) % 4096 - 4096:][:0], y[0, :0])
     tail = M % 4096
     assert np.array_equal(y[0, M - tail:].view(np.uint32), y[0, :tail].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------
+# decode plan: a chain of N=1 mul_mats as ONE persistent launch (mi355q_plan_*)
+# ------------------------------------------------------------------------------------------------
+def _bits_t(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("t", FAST, ids=ids_t)
+def test_plan_dependent_chain_bitexact(G, torch, orc, t):
+    """y of every stage IS x of the next one (the grid barrier and the agent-scope stores/loads carry real
+    data between workgroups on different XCDs); every stage must equal the per-matmul launch bit for bit
+    and the oracle within tolerance.  Re-run several times: the barrier counters re-arm themselves."""
+    rng = np.random.default_rng(21 + t)
+    K = 2048
+    hosts = [quantized_weights(t, K, K, rng, scale=0.05) for _ in range(5)]
+    ws = [G.QWeight.from_host(t, h, K, K) for h in hosts]
+    x0 = torch.from_numpy(rng.standard_normal((1, K)).astype(np.float32)).cuda()
+    bufs = [x0] + [torch.zeros((1, K), dtype=torch.float32, device="cuda") for _ in ws]
+    refs = [x0]
+    for w in ws:
+        refs.append(G.mul_mat(w, refs[-1]))
+    plan = G.Plan([([w], bufs[i], [bufs[i + 1]], i > 0) for i, w in enumerate(ws)])
+    assert plan.weight_bytes == sum(w.nbytes for w in ws)
+    for rep in range(4):
+        for b in bufs[1:]:
+            b.zero_()
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        for i in range(len(ws)):
+            assert np.array_equal(_bits_t(bufs[i + 1]), _bits_t(refs[i + 1])), (rep, i)
+    xin = x0.cpu().numpy()
+    for i, h in enumerate(hosts):                              # and against the oracle, stage by stage on the device's own inputs
+        check_close(bufs[i + 1].cpu().numpy(), orc.mul_mat(t, h, xin, K, 1, K), f"stage {i}")
+        xin = bufs[i + 1].cpu().numpy()
+    plan.close()
+
+
+def test_plan_llama_layer_mixed_types(G, torch, orc):
+    """One Q4_K_M-shaped layer at reduced width: wq|wk (Q4_K) + wv (Q6_K) on one x, wo, gate|up, down (Q6_K, K != n_embd),
+    ragged row counts (not multiples of 16 or of the CU count), independent activation buffers per stage."""
+    rng = np.random.default_rng(77)
+    E, F, KV = 2048, 2816, 264                              # Q6_K rows are planar when k % 2048 == 0
+    def W(t, m, k):
+        h = quantized_weights(t, m, k, rng)
+        return h, G.QWeight.from_host(t, h, m, k)
+    layer = [[W(oracle.Q4_K, E, E), W(oracle.Q4_K, KV, E), W(oracle.Q6_K, KV, E)], [W(oracle.Q4_K, E, E)],
+             [W(oracle.Q4_K, F, E), W(oracle.Q4_K, F, E)], [W(oracle.Q6_K, E, 4096)]]
+    stages, checks = [], []
+    for gi, grp in enumerate(layer):
+        k = grp[0][1].K
+        x = torch.from_numpy(rng.standard_normal((1, k)).astype(np.float32)).cuda()
+        ys = [torch.zeros((1, w.M), dtype=torch.float32, device="cuda") for _, w in grp]
+        stages.append(([w for _, w in grp], x, ys, gi > 0))
+        checks.append((grp, x, ys))
+    plan = G.Plan(stages)
+    assert plan.launch_stages == 5                             # the mixed-type first stage is split per type
+    plan.run(); torch.cuda.synchronize()
+    assert plan.status() == 0
+    for grp, x, ys in checks:
+        for (h, w), y in zip(grp, ys):
+            assert np.array_equal(_bits_t(y), _bits_t(G.mul_mat(w, x)))
+            check_close(y.cpu().numpy(), orc.mul_mat(w.type, h, x.cpu().numpy(), w.M, 1, w.K))
+    plan.close()
+
+
+def test_plan_rejects_what_it_cannot_stream(G, torch):
+    rng = np.random.default_rng(5)
+    w = G.QWeight.from_host(oracle.Q3_K, random_blocks(oracle.Q3_K, 32, 256, rng), 32, 256)      # no planar streamer for Q3_K
+    x = torch.zeros((1, 256), dtype=torch.float32, device="cuda"); y = torch.zeros((1, 32), dtype=torch.float32, device="cuda")
+    with pytest.raises(G.Mi355qError):
+        G.Plan([([w], x, [y], False)])
+    w6 = G.QWeight.from_host(oracle.Q6_K, random_blocks(oracle.Q6_K, 32, 256, rng), 32, 256)      # Q6_K rows of 210 bytes are not planar at k=256
+    with pytest.raises(G.Mi355qError):
+        G.Plan([([w6], x, [y], False)])

@@ -14,11 +14,12 @@ import bench as B
 ap = argparse.ArgumentParser()
 ap.add_argument("--ftype", default="Q4_K_M"); ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--layers", type=int, default=32); ap.add_argument("--no-depends", action="store_true")
+ap.add_argument("--no-check", action="store_true", help="timing only (debug modes that produce garbage)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 
 # ---- correctness: a true chain, square matrices, y_s is x_{s+1}
-for t in (g.Q4_K, g.Q6_K, g.Q8_0):
+for t in (() if a.no_check else (g.Q4_K, g.Q6_K, g.Q8_0)):
     K = 4096
     class S: pass
     ws = []
