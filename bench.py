@@ -302,8 +302,21 @@ def main():
             dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["bytes_per_token"])
             all_kernels = per_kernel
         achieved = dom["GBps"]
+        # HBM bytes per launch from the PMC pass of this same command (rocprofv3 cannot run inside the timed process; the
+        # committed summary of the separate --pmc FETCH_SIZE pass is quoted, with its source, when it covers this kernel)
+        traffic, traffic_src = None, None
+        if plan is not None and a.ftype == "Q4_K_M" and world == 1:
+            for tf in sorted((ROOT / "profiles").glob("round*_traffic.json"), reverse=True):
+                try:
+                    tj = json.loads(tf.read_text())
+                    vals = [v for k, v in tj.get("kernels", {}).items() if k.startswith("k_plan")]
+                    if vals:
+                        traffic, traffic_src = int(vals[0]), f"{tj.get('source')}: {tj.get('method')}"
+                        break
+                except Exception:
+                    pass
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "kernel": dom_name, "launches_per_token": dom["launches_per_token"],
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
                            "whole_token_GBps": round(total_bytes * a.steps / dt / 1e9, 1) if world == 1 else None,
@@ -316,6 +329,8 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
+    if not a.dry_run and plan is not None:
+        plan.close()                                            # before interpreter teardown (the HIP runtime unloads first under profilers)
     if world > 1:
         dist.destroy_process_group()
 

@@ -273,6 +273,9 @@ class Plan:
             self._h = None
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():     # the HIP runtime may already be gone: leave the device memory to process teardown
+            return
         try:
             self.close()
         except Exception:
