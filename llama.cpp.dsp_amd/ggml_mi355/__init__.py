@@ -17,6 +17,7 @@ but every compute call raises if libmi355q.so or a gfx950 device is missing.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -272,9 +273,8 @@ class Plan:
             lib().mi355q_plan_destroy(self._h)
             self._h = None
 
-    def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():     # the HIP runtime may already be gone: leave the device memory to process teardown
+    def __del__(self, _sys=sys):
+        if _sys is None or _sys.is_finalizing():     # the HIP runtime may already be gone: leave the device memory to process teardown
             return
         try:
             self.close()
