@@ -26,8 +26,10 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float  f32x2;
 typedef __attribute__((ext_vector_type(4))) float  f32x4;
 
-constexpr int MMQ_BM = 128, MMQ_BK = 128, MMQ_THREADS = 256;   // BN (tokens per tile) is a template parameter: 128 or 64
-constexpr int MMQ_LDS_STRIDE = (MMQ_BK + 8) * 2;          // bytes per LDS row (16-byte pad)
+constexpr int MMQ_BK = 128, MMQ_THREADS = 256;            // BM x BN (rows x tokens per tile) are template parameters: 128x128, 128x64, 64x64
+constexpr int MMQ_LDS_STRIDE = (MMQ_BK + 8) * 2;          // bytes per LDS row: 256 + 16 pad -> the 16 rows of a fragment read hit 16 distinct bank groups
+
+typedef __attribute__((ext_vector_type(2))) float f32x2p;
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     const f32x2 v = { a, b };
@@ -46,225 +48,224 @@ k_x_to_bf16(const float * __restrict__ x, int64_t x_stride, uint32_t * __restric
     }
 }
 
-// ---- per-type: packed bytes of 64 consecutive k of one row -> 64 f32 weights -----------------------
-// `row` = planar device row, nb = blocks per row, ks = 128-element step index, sub = which 64 of the step.
-// load() only issues global loads (so the caller can run them ahead of the MFMAs); dequant() consumes them.
-template <int T> struct W64;
+// 4 unsigned bytes of a dword -> a*byte + c as 4 floats -> 2 packed bf16 dwords.  v_cvt_f32_ubyteN (one op per weight),
+// v_pk_fma_f32 (two weights per op), v_cvt_pk_bf16_f32 (two per op): 2 ops per weight, the rest is per-dword bit twiddling.
+__device__ __forceinline__ void bytes4_to_bf16(uint32_t v, float a, float c, uint32_t & lo, uint32_t & hi) {
+    const f32x2p q01 = { (float) (v & 0xFFu), (float) ((v >> 8) & 0xFFu) };          // the compiler selects v_cvt_f32_ubyte0..3 for these
+    const f32x2p q23 = { (float) ((v >> 16) & 0xFFu), (float) (v >> 24) };
+    const f32x2p aa = { a, a }, cc = { c, c };
+    const f32x2p w01 = __builtin_elementwise_fma(q01, aa, cc), w23 = __builtin_elementwise_fma(q23, aa, cc);
+    lo = pack_bf16(w01.x, w01.y); hi = pack_bf16(w23.x, w23.y);
+}
 
-template <> struct W64<MI355Q_TYPE_Q4_K> {          // planar [qs 128*nb][hdr 16*nb]
-    uint4 q0, q1, h;
+// ---- per type: the packed bytes of 32 consecutive k of one row -> 32 bf16 (16 dwords) ----------------
+// `row` = planar device row, nb = blocks per row, ks = 64-element step index, sub = which 32 of the step.
+// load() only issues global loads (so the caller can run them ahead of the MFMAs); dequant() consumes them.
+// w = d*sc*q - dmin*m etc. exactly as dequantize_row_* (ggml-quants.c), evaluated as one f32 FMA per weight.
+template <int T> struct W32;
+#define W32_DEQUANT16 \
+    __device__ __forceinline__ void dequant16(uint32_t & o0, uint32_t & o1, uint32_t & o2, uint32_t & o3, uint32_t & o4, uint32_t & o5, uint32_t & o6, uint32_t & o7, \
+                                              uint32_t & o8, uint32_t & o9, uint32_t & o10, uint32_t & o11, uint32_t & o12, uint32_t & o13, uint32_t & o14, uint32_t & o15) const { \
+        uint32_t t[16]; dequant(t); \
+        o0 = t[0]; o1 = t[1]; o2 = t[2]; o3 = t[3]; o4 = t[4]; o5 = t[5]; o6 = t[6]; o7 = t[7]; \
+        o8 = t[8]; o9 = t[9]; o10 = t[10]; o11 = t[11]; o12 = t[12]; o13 = t[13]; o14 = t[14]; o15 = t[15]; }
+
+template <> struct W32<MI355Q_TYPE_Q4_K> {          // planar [qs 128*nb][hdr 16*nb]; step = 64-group g of block b: low nibbles = first 32, high = last 32
+    W32_DEQUANT16
+    uint4 q0, q1, h; int j, sh;
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
-        const int b = ks >> 1, g = 2 * (ks & 1) + sub;                   // 64-group g of block b: qs bytes 32g..32g+31
+        const int b = ks >> 2, g = ks & 3;
         const uint8_t * p = row + 128 * (int64_t) b + 32 * g;
         q0 = ldg16_nt(p); q1 = ldg16_nt(p + 16);
         h  = ldg16(row + 128 * (int64_t) nb + 16 * b);
-        gsel = g;
+        j = 2 * g + sub; sh = 4 * sub;
     }
-    int gsel;
-    __device__ __forceinline__ void dequant(float * w) const {          // dequantize_row_q4_K, ggml-quants.c:1280-1302
-        const float d = h2f(h.x & 0xFFFFu), dmin = h2f(h.x >> 16);
-        int sc0, mn0, sc1, mn1;
-        k4_scale_min(h.y, h.z, h.w, 2 * gsel, sc0, mn0);
-        k4_scale_min(h.y, h.z, h.w, 2 * gsel + 1, sc1, mn1);
-        const float d1 = d * (float) sc0, m1 = dmin * (float) mn0, d2 = d * (float) sc1, m2 = dmin * (float) mn1;
+    __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_q4_K, ggml-quants.c:1280-1302
+        int sc, mn; k4_scale_min(h.y, h.z, h.w, j, sc, mn);
+        const float a = h2f(h.x & 0xFFFFu) * (float) sc, c = -(h2f(h.x >> 16) * (float) mn);
         const uint32_t qw[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t byte = (qw[i] >> (8 * j)) & 0xFFu;
-                w[4 * i + j]      = d1 * (float) (byte & 0x0Fu) - m1;
-                w[32 + 4 * i + j] = d2 * (float) (byte >> 4) - m2;
-            }
+        for (int i = 0; i < 8; ++i) bytes4_to_bf16((qw[i] >> sh) & 0x0F0F0F0Fu, a, c, out[2 * i], out[2 * i + 1]);
     }
 };
 
-template <> struct W64<MI355Q_TYPE_Q5_K> {          // planar [qs 128*nb][qh 32*nb][hdr 16*nb]
-    uint4 q0, q1, b0, b1, h; int gsel;
+template <> struct W32<MI355Q_TYPE_Q5_K> {          // planar [qs 128*nb][qh 32*nb][hdr 16*nb]
+    W32_DEQUANT16
+    uint4 q0, q1, b0, b1, h; int j, sh;
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
-        const int b = ks >> 1, g = 2 * (ks & 1) + sub;
+        const int b = ks >> 2, g = ks & 3;
         const uint8_t * p = row + 128 * (int64_t) b + 32 * g;
         q0 = ldg16_nt(p); q1 = ldg16_nt(p + 16);
         const uint8_t * qh = row + 128 * (int64_t) nb + 32 * b;
         b0 = ldg16(qh); b1 = ldg16(qh + 16);
         h  = ldg16(row + 160 * (int64_t) nb + 16 * b);
-        gsel = g;
+        j = 2 * g + sub; sh = 4 * sub;
     }
-    __device__ __forceinline__ void dequant(float * w) const {          // dequantize_row_q5_K, ggml-quants.c:1482-1507
-        const float d = h2f(h.x & 0xFFFFu), dmin = h2f(h.x >> 16);
-        int sc0, mn0, sc1, mn1;
-        k4_scale_min(h.y, h.z, h.w, 2 * gsel, sc0, mn0);
-        k4_scale_min(h.y, h.z, h.w, 2 * gsel + 1, sc1, mn1);
-        const float d1 = d * (float) sc0, m1 = dmin * (float) mn0, d2 = d * (float) sc1, m2 = dmin * (float) mn1;
+    __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_q5_K, ggml-quants.c:1482-1507
+        int sc, mn; k4_scale_min(h.y, h.z, h.w, j, sc, mn);
+        const float a = h2f(h.x & 0xFFFFu) * (float) sc, c = -(h2f(h.x >> 16) * (float) mn);
         const uint32_t qw[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
         const uint32_t hw[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t byte = (qw[i] >> (8 * j)) & 0xFFu, hb = (hw[i] >> (8 * j)) & 0xFFu;
-                w[4 * i + j]      = d1 * (float) ((byte & 0x0Fu) + (((hb >> (2 * gsel)) & 1u) << 4)) - m1;
-                w[32 + 4 * i + j] = d2 * (float) ((byte >> 4) + (((hb >> (2 * gsel + 1)) & 1u) << 4)) - m2;
-            }
+            bytes4_to_bf16(((qw[i] >> sh) & 0x0F0F0F0Fu) | (((hw[i] >> j) & 0x01010101u) << 4), a, c, out[2 * i], out[2 * i + 1]);
     }
 };
 
-template <> struct W64<MI355Q_TYPE_Q6_K> {          // planar [ql 128*nb][qh 64*nb][scales 16*nb PERMUTED][d 2*nb]
-    uint4 l0, l1, l2, l3, h0, h1, sc; uint32_t dh; int hsel, ssel;
+template <> struct W32<MI355Q_TYPE_Q6_K> {          // planar [ql 128*nb][qh 64*nb][scales 16*nb PERMUTED][d 2*nb]
+    W32_DEQUANT16
+    uint4 l0, l1, h0, h1, sc; uint32_t dh; int s0, nsh, fsh;
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
-        const int b = ks >> 1, hh = ks & 1;                              // half hh of block b; sub 0: low nibbles, 1: high nibbles
-        const uint8_t * ql = row + 128 * (int64_t) b + 64 * hh;
-        l0 = ldg16_nt(ql); l1 = ldg16_nt(ql + 16); l2 = ldg16_nt(ql + 32); l3 = ldg16_nt(ql + 48);
+        // block b, 128-half hh, nibble nib (0: elements 0..63 of the half, 1: 64..127), 32-run sub:
+        // ql bytes 64*hh + 32*sub + l (nibble nib), qh bytes 32*hh + l, 2-bit field 2*nib + sub      (ggml-quants.c:1690-1719)
+        const int b = ks >> 2, hh = (ks >> 1) & 1, nib = ks & 1;
+        const uint8_t * ql = row + 128 * (int64_t) b + 64 * hh + 32 * sub;
+        l0 = ldg16_nt(ql); l1 = ldg16_nt(ql + 16);
         const uint8_t * qh = row + 128 * (int64_t) nb + 64 * b + 32 * hh;
         h0 = ldg16(qh); h1 = ldg16(qh + 16);
         sc = ldg16(row + 192 * (int64_t) nb + 16 * b);
         dh = *(const uint16_t *) (row + 208 * (int64_t) nb + 2 * b);
-        hsel = hh; ssel = sub;
+        s0 = 8 * hh + 4 * nib + 2 * sub; nsh = 4 * nib; fsh = 2 * (2 * nib + sub);
     }
     // scale of sub-block s (0..15) from the permuted 16-byte group (layout.hip: device byte 2j <- 8h+2cc+p, 2j+1 <- +4)
     __device__ __forceinline__ int scale(int s) const {
-        const int hh = s >> 3, t = s & 7, hi = t >> 2, j = 4 * hh + (t & 3);
-        const int dev = 2 * j + hi;
-        const uint32_t wv = dev < 4 ? sc.x : (dev < 8 ? sc.y : (dev < 12 ? sc.z : sc.w));
-        return (int) (int8_t) ((wv >> (8 * (dev & 3))) & 0xFFu);
+        const int hh = s >> 3, t = s & 7, hi = t >> 2, jj = 4 * hh + (t & 3);
+        const int dev = 2 * jj + hi;
+        // 64-bit shifts, not a 4-way select between the fields: the compiler turns that into an indexed load from a scratch copy
+        const uint64_t lo = (uint64_t) sc.x | ((uint64_t) sc.y << 32), hi64 = (uint64_t) sc.z | ((uint64_t) sc.w << 32);
+        return (int) (int8_t) (((dev < 8 ? lo : hi64) >> (8 * (dev & 7))) & 0xFFu);
     }
-    __device__ __forceinline__ void dequant(float * w) const {          // dequantize_row_q6_K, ggml-quants.c:1690-1719
+    __device__ __forceinline__ void dequant(uint32_t * out) const {
         const float d = h2f(dh);
-        const uint32_t lw[16] = { l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w };
-        const uint32_t hw[8]  = { h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w };
-        float dsc[4];
+        const float a0 = d * (float) scale(s0), a1 = d * (float) scale(s0 + 1);      // 16 elements each
+        const uint32_t lw[8] = { l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w };
+        const uint32_t hw[8] = { h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dsc[i] = d * (float) scale(8 * hsel + 4 * ssel + i);
-        // element e (0..63) of this 64-run: ql byte e, qh byte e & 31, 2-bit field 2*(e>>5) (+4 for the high nibbles)
-#pragma unroll
-        for (int e = 0; e < 64; ++e) {
-            const uint32_t lb = (lw[e >> 2] >> (8 * (e & 3))) & 0xFFu;
-            const uint32_t hb = (hw[(e & 31) >> 2] >> (8 * (e & 3))) & 0xFFu;
-            const uint32_t lo4 = ssel ? (lb >> 4) : (lb & 0x0Fu);
-            const uint32_t hi2 = (hb >> (2 * (e >> 5) + 4 * ssel)) & 3u;
-            w[e] = dsc[e >> 4] * (float) ((int) (lo4 | (hi2 << 4)) - 32);
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t q = ((lw[i] >> nsh) & 0x0F0F0F0Fu) | (((hw[i] >> fsh) & 0x03030303u) << 4);
+            const float a = i < 4 ? a0 : a1;
+            bytes4_to_bf16(q, a, -32.0f * a, out[2 * i], out[2 * i + 1]);
         }
     }
 };
 
-template <> struct W64<MI355Q_TYPE_Q8_0> {          // planar [qs 32*nb][d 2*nb]; 64 k = 2 blocks
-    uint4 q0, q1, q2, q3; uint32_t d01;
+template <> struct W32<MI355Q_TYPE_Q8_0> {          // planar [qs 32*nb][d 2*nb]; 32 k = 1 block
+    W32_DEQUANT16
+    uint4 q0, q1; uint32_t dh;
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
-        const int b = 4 * ks + 2 * sub;
+        const int b = 2 * ks + sub;
         const uint8_t * p = row + 32 * (int64_t) b;
-        q0 = ldg16_nt(p); q1 = ldg16_nt(p + 16); q2 = ldg16_nt(p + 32); q3 = ldg16_nt(p + 48);
-        d01 = *(const uint32_t *) (row + 32 * (int64_t) nb + 2 * b);     // two f16 scales (b is even: 4-byte aligned)
-    }
-    __device__ __forceinline__ void dequant(float * w) const {          // dequantize_row_q8_0, ggml-quants.c:349-363
-        const float d0 = h2f(d01 & 0xFFFFu), d1 = h2f(d01 >> 16);
-        const uint32_t qw[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
-#pragma unroll
-        for (int e = 0; e < 64; ++e) {
-            const int q = (int) (int8_t) ((qw[e >> 2] >> (8 * (e & 3))) & 0xFFu);
-            w[e] = (float) q * (e < 32 ? d0 : d1);
-        }
-    }
-};
-
-template <> struct W64<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]; 64 k = 2 blocks
-    uint4 q0, q1; uint32_t d01;
-    __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
-        const int b = 4 * ks + 2 * sub;
-        const uint8_t * p = row + 16 * (int64_t) b;
         q0 = ldg16_nt(p); q1 = ldg16_nt(p + 16);
-        d01 = *(const uint32_t *) (row + 16 * (int64_t) nb + 2 * b);
+        dh = *(const uint16_t *) (row + 32 * (int64_t) nb + 2 * b);
     }
-    __device__ __forceinline__ void dequant(float * w) const {          // dequantize_row_q4_0, ggml-quants.c:255-273
-        const float d[2] = { h2f(d01 & 0xFFFFu), h2f(d01 >> 16) };
+    __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_q8_0, ggml-quants.c:349-363
+        const float d = h2f(dh);
         const uint32_t qw[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int i = 0; i < 8; ++i) bytes4_to_bf16(qw[i] ^ 0x80808080u, d, -128.0f * d, out[2 * i], out[2 * i + 1]);   // int8 = (uint8 ^ 0x80) - 128
+    }
+};
+
+template <> struct W32<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]; 32 k = 1 block: low nibbles = first 16, high = last 16
+    W32_DEQUANT16
+    uint4 q0; uint32_t dh;
+    __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
+        const int b = 2 * ks + sub;
+        q0 = ldg16_nt(row + 16 * (int64_t) b);
+        dh = *(const uint16_t *) (row + 16 * (int64_t) nb + 2 * b);
+    }
+    __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_q4_0, ggml-quants.c:255-273
+        const float d = h2f(dh);
+        const uint32_t qw[4] = { q0.x, q0.y, q0.z, q0.w };
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t byte = (qw[4 * blk + (j >> 2)] >> (8 * (j & 3))) & 0xFFu;
-                w[32 * blk + j]      = (float) ((int) (byte & 0x0Fu) - 8) * d[blk];
-                w[32 * blk + 16 + j] = (float) ((int) (byte >> 4) - 8) * d[blk];
-            }
+        for (int i = 0; i < 4; ++i) {
+            bytes4_to_bf16(qw[i] & 0x0F0F0F0Fu, d, -8.0f * d, out[2 * i], out[2 * i + 1]);
+            bytes4_to_bf16((qw[i] >> 4) & 0x0F0F0F0Fu, d, -8.0f * d, out[8 + 2 * i], out[8 + 2 * i + 1]);
+        }
     }
 };
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <int T, int MMQ_BN>
-__global__ void __launch_bounds__(MMQ_THREADS, 2)
+// Tile BM x BN x 128; 256 threads = 2 x 2 waves, each a (BM/2) x (BN/2) output tile of 16x16x32 MFMAs.  Thread jobs per
+// K-step: BM*4/256 dequant units (row, 32-k quarter) and BN*4/256 activation quarters (64 B).  Shapes that would leave
+// CUs idle or with a single workgroup (one wave per SIMD hides no latency) get smaller tiles: 64 x 64 tiles need 35 KiB
+// of LDS, so four workgroups share a CU.
+template <int T, int MMQ_BM, int MMQ_BN>
+__global__ void __launch_bounds__(MMQ_THREADS, (MMQ_BM == 64 && MMQ_BN == 64) ? 4 : 2)
 k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __restrict__ xb /* bf16 [n][k] */,
            float * __restrict__ y, int64_t y_stride, int m, int n, int k) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // 2 * 128 * 272 B = 68 KiB (> the 64 KiB static limit)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t * Ws = lds;
     uint8_t * Xs = lds + MMQ_BM * MMQ_LDS_STRIDE;                          // BN rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                              // 2 x 2 waves, 64 x (BN/2) each
-    constexpr int WN = MMQ_BN / 2, NT = WN / 16;                          // tokens per wave, 16-token MFMA tiles per wave
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int WM = MMQ_BM / 2, WN = MMQ_BN / 2, MT = WM / 16, NT = WN / 16;
+    constexpr int UW = MMQ_BM * 4 / MMQ_THREADS, UX = MMQ_BN * 4 / MMQ_THREADS;
     const int m0 = blockIdx.x * MMQ_BM, n0 = blockIdx.y * MMQ_BN;
     const int nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
     const int steps = k / MMQ_BK;
 
-    // this thread's dequant job: row m0 + tid/2, k half tid%2
-    const int  wr = tid >> 1, wsub = tid & 1;
-    const bool wvalid = m0 + wr < m;
-    const uint8_t * wrow = w + (int64_t) (wvalid ? m0 + wr : 0) * w_stride;
-    // this thread's activation staging job: token n0 + tid/2, 64 k (128 B) at k half tid%2
-    const int  xr = tid >> 1, xsub = tid & 1;
-    const bool xvalid = xr < MMQ_BN && n0 + xr < n;
-    const uint16_t * xrow = xb + (int64_t) (xvalid ? n0 + xr : 0) * k + 64 * xsub;
+    // dequant units: (row, quarter) = ((tid + 256 u) >> 2, tid & 3), u < UW; out-of-range rows read row 0 (never stored).
+    // (Named variables, not arrays indexed by u: the compiler leaves such small arrays in scratch memory.)
+    const int quarter = tid & 3, r0 = tid >> 2, r1 = (tid + MMQ_THREADS) >> 2;
+    const uint8_t * wrow0 = w + (int64_t) (m0 + r0 < m ? m0 + r0 : 0) * w_stride;
+    const uint8_t * wrow1 = w + (int64_t) (m0 + r1 < m ? m0 + r1 : 0) * w_stride;
+    const uint16_t * xrow0 = xb + (int64_t) (n0 + r0 < n ? n0 + r0 : 0) * k + 32 * quarter;
+    const uint16_t * xrow1 = xb + (int64_t) (n0 + r1 < n ? n0 + r1 : 0) * k + 32 * quarter;
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4) { 0.f, 0.f, 0.f, 0.f };
 
-    W64<T> wq;
-    uint4 xv[8];
-    if (wvalid) wq.load(wrow, nb, 0, wsub);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xv[i] = xvalid ? *(const uint4 *) (xrow + 8 * i) : make_uint4(0, 0, 0, 0);
+    W32<T> wq0, wq1;
+    uint4 xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
+    auto fetch = [&](int kn) {                                // packed weights + bf16 activations of K-step kn -> registers
+        wq0.load(wrow0, nb, 2 * kn + (quarter >> 1), quarter & 1);
+        if constexpr (UW > 1) wq1.load(wrow1, nb, 2 * kn + (quarter >> 1), quarter & 1);
+        const uint16_t * p0 = xrow0 + (int64_t) kn * MMQ_BK;
+        xa0 = *(const uint4 *) p0; xa1 = *(const uint4 *) (p0 + 8); xa2 = *(const uint4 *) (p0 + 16); xa3 = *(const uint4 *) (p0 + 24);
+        if constexpr (UX > 1) {
+            const uint16_t * p1 = xrow1 + (int64_t) kn * MMQ_BK;
+            xb0 = *(const uint4 *) p1; xb1 = *(const uint4 *) (p1 + 8); xb2 = *(const uint4 *) (p1 + 16); xb3 = *(const uint4 *) (p1 + 24);
+        }
+    };
+    auto stage_w = [&](const W32<T> & q, int r) {             // dequantize one unit into the bf16 W tile
+        uint32_t b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
+        q.dequant16(b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15);
+        uint8_t * dst = Ws + r * MMQ_LDS_STRIDE + 64 * quarter;
+        *(uint4 *) (dst)      = make_uint4(b0, b1, b2, b3);   *(uint4 *) (dst + 16) = make_uint4(b4, b5, b6, b7);
+        *(uint4 *) (dst + 32) = make_uint4(b8, b9, b10, b11); *(uint4 *) (dst + 48) = make_uint4(b12, b13, b14, b15);
+    };
+    fetch(0);
 
     for (int ks = 0; ks < steps; ++ks) {
         // ---- stage step ks into LDS (registers were loaded one step ahead) ----
+        stage_w(wq0, r0);
+        if constexpr (UW > 1) stage_w(wq1, r1);
         {
-            float wf[64];
-            if (wvalid) wq.dequant(wf);
-            else {
-#pragma unroll
-                for (int e = 0; e < 64; ++e) wf[e] = 0.0f;
-            }
-            uint8_t * dst = Ws + wr * MMQ_LDS_STRIDE + 128 * wsub;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint4 v;
-                v.x = pack_bf16(wf[8 * i], wf[8 * i + 1]); v.y = pack_bf16(wf[8 * i + 2], wf[8 * i + 3]);
-                v.z = pack_bf16(wf[8 * i + 4], wf[8 * i + 5]); v.w = pack_bf16(wf[8 * i + 6], wf[8 * i + 7]);
-                *(uint4 *) (dst + 16 * i) = v;
-            }
-            if (xr < MMQ_BN) {
-                uint8_t * xdst = Xs + xr * MMQ_LDS_STRIDE + 128 * xsub;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) *(uint4 *) (xdst + 16 * i) = xv[i];
-            }
+            uint8_t * xdst = Xs + r0 * MMQ_LDS_STRIDE + 64 * quarter;
+            *(uint4 *) xdst = xa0; *(uint4 *) (xdst + 16) = xa1; *(uint4 *) (xdst + 32) = xa2; *(uint4 *) (xdst + 48) = xa3;
+        }
+        if constexpr (UX > 1) {
+            uint8_t * xdst = Xs + r1 * MMQ_LDS_STRIDE + 64 * quarter;
+            *(uint4 *) xdst = xb0; *(uint4 *) (xdst + 16) = xb1; *(uint4 *) (xdst + 32) = xb2; *(uint4 *) (xdst + 48) = xb3;
         }
         __syncthreads();
-        // ---- prefetch step ks+1 while the matrix cores work on step ks ----
-        if (ks + 1 < steps) {
-            if (wvalid) wq.load(wrow, nb, ks + 1, wsub);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xv[i] = xvalid ? *(const uint4 *) (xrow + (int64_t) (ks + 1) * MMQ_BK + 8 * i) : make_uint4(0, 0, 0, 0);
-        }
+        // ---- prefetch step ks+1 while the matrix cores work on step ks (the last step re-reads itself: no branch) ----
+        fetch(ks + 1 < steps ? ks + 1 : ks);
         // ---- 4 k-slices of 32: A = W rows (lane: row l&15, k 8*(l>>4)..+7), B = tokens (lane: col l&15, same k) ----
 #pragma unroll
         for (int kk = 0; kk < MMQ_BK / 32; ++kk) {
-            bf16x8 af[4], bfr[NT];
+            bf16x8 af[MT], bfr[NT];
             const int koff = 2 * (32 * kk + 8 * (lane >> 4));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i]  = *(const bf16x8 *) (Ws + (64 * wm + 16 * i + (lane & 15)) * MMQ_LDS_STRIDE + koff);
+            for (int i = 0; i < MT; ++i) af[i]  = *(const bf16x8 *) (Ws + (WM * wm + 16 * i + (lane & 15)) * MMQ_LDS_STRIDE + koff);
 #pragma unroll
             for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8 *) (Xs + (WN * wn + 16 * j + (lane & 15)) * MMQ_LDS_STRIDE + koff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
@@ -278,8 +279,8 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
         if (tok >= n) continue;
         float * yr = (float *) ((char *) y + (int64_t) tok * y_stride);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int mr = m0 + 64 * wm + 16 * i + 4 * (lane >> 4);
+        for (int i = 0; i < MT; ++i) {
+            const int mr = m0 + WM * wm + 16 * i + 4 * (lane >> 4);
             if (mr + 3 < m) *(f32x4 *) (yr + mr) = acc[i][j];
             else {
 #pragma unroll
@@ -309,22 +310,25 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     const int64_t pairs = n * k / 2;
     const int cgrid = (int) ((pairs + 255) / 256 < 8192 ? (pairs + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_x_to_bf16, dim3(cgrid), dim3(256), 0, stream, x, x_stride, (uint32_t *) workspace, n, k);
-    // 128-token tiles amortize the dequantization best; when that leaves CUs idle (M = 4096, N = 512 is only 128 tiles
-    // for 256 CUs) use 64-token tiles.
-    const int64_t tiles128 = ((m + MMQ_BM - 1) / MMQ_BM) * ((n + 127) / 128);
-    const int bn = (tiles128 < (int64_t) n_cu && n > 64) ? 64 : 128;
-    const dim3 grid((unsigned) ((m + MMQ_BM - 1) / MMQ_BM), (unsigned) ((n + bn - 1) / bn));
-#define MI355Q_MMQ_LAUNCH(T, BN) {                                                                                                 \
-        constexpr size_t lds_bytes = (size_t) (MMQ_BM + BN) * MMQ_LDS_STRIDE;                                                      \
+    // The largest tile that still gives every CU about three workgroups: 128 x 128 amortizes the dequantization best, but a
+    // pp512 matmul of a 4096-row matrix is only 128 such tiles for 256 CUs; one workgroup per CU (one wave per SIMD) hides no
+    // latency at all.
+    auto tiles = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
+    int bm = 64, bn = 64;                                     // measured on pp512 shapes: 128x128 wins from ~1.5 workgroups per CU on
+    if (2 * tiles(128, 128) >= 3 * (int64_t) n_cu) { bm = 128; bn = 128; }
+    else if (tiles(128, 64) >= 2 * (int64_t) n_cu) { bm = 128; bn = 64; }
+    const dim3 grid((unsigned) ((m + bm - 1) / bm), (unsigned) ((n + bn - 1) / bn));
+#define MI355Q_MMQ_LAUNCH(T, BM, BN) {                                                                                             \
+        constexpr size_t lds_bytes = (size_t) (BM + BN) * MMQ_LDS_STRIDE;          /* 68 / 51 / 34 KiB */                           \
         static bool attr_set = false;                                                                                              \
         if (!attr_set) {                                                                                                           \
-            if (hipFuncSetAttribute((const void *) k_mmq_bf16<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess) \
+            if (hipFuncSetAttribute((const void *) k_mmq_bf16<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess) \
                 return MI355Q_ERR_HIP;                                                                                             \
             attr_set = true;                                                                                                       \
         }                                                                                                                          \
-        hipLaunchKernelGGL((k_mmq_bf16<T, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,         \
+        hipLaunchKernelGGL((k_mmq_bf16<T, BM, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,     \
                            (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k); }
-#define MI355Q_MMQ_CASE(T) case T: if (bn == 64) MI355Q_MMQ_LAUNCH(T, 64) else MI355Q_MMQ_LAUNCH(T, 128) break;
+#define MI355Q_MMQ_CASE(T) case T: if (bm == 128 && bn == 128) MI355Q_MMQ_LAUNCH(T, 128, 128) else if (bm == 128) MI355Q_MMQ_LAUNCH(T, 128, 64) else MI355Q_MMQ_LAUNCH(T, 64, 64) break;
     switch (type) {
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q5_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q6_K)
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q8_0) MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_0)
