@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=128)     # tg128
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--ftype", default="Q4_K_M", choices=["Q4_K_M", "Q8_0"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "mixtral-8x7b"],
+                    help="BASELINE.json configs: the headline is llama3-8b; mixtral-8x7b exercises MUL_MAT_ID (per-matmul launches)")
+    ap.add_argument("--no-pp", action="store_true", help="skip the pp512 (MFMA tier) measurement")
     ap.add_argument("--launch", default="plan", choices=["plan", "graph", "eager"],
                     help="plan: one persistent launch per token (default); graph: 129 launches in a hipGraph; eager: 129 plain launches")
     ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
@@ -55,21 +58,27 @@ def parse():
 # ---------------------------------------------------------------------------------------------------
 def device_random_weight(torch, g, spec, device):
     """Random VALID packed rows generated on the device (random payload bytes, finite f16 scales),
-    then converted to the device layout with mi355q_weights_pack_d2d."""
-    bs = {g.Q4_K: 144, g.Q6_K: 210, g.Q8_0: 34}[spec.type]
+    then converted to the device layout with mi355q_weights_pack_d2d.  Expert tensors: n_expert matrices back to back."""
+    bs = {g.Q4_K: 144, g.Q5_K: 176, g.Q6_K: 210, g.Q8_0: 34}[spec.type]
     blck = 32 if spec.type == g.Q8_0 else 256
     nb = spec.K // blck
-    raw = torch.randint(0, 256, (spec.M, nb, bs), dtype=torch.uint8, device=device)
-    for off in {g.Q4_K: (0, 2), g.Q6_K: (208,), g.Q8_0: (0,)}[spec.type]:
-        sc = (torch.rand((spec.M, nb), device=device) * 0.02 + 1e-3).to(torch.float16)
-        raw[:, :, off:off + 2] = sc.view(torch.uint8).view(spec.M, nb, 2)
-    dst = torch.empty(spec.nbytes + 64, dtype=torch.uint8, device=device)
-    rc = g.lib().mi355q_weights_pack_d2d(spec.type, dst.data_ptr(), raw.data_ptr(), spec.M, spec.K,
-                                         int(torch.cuda.current_stream().cuda_stream))
-    if rc != 0:
-        raise RuntimeError(g.lib().mi355q_last_error().decode())
-    torch.cuda.synchronize()
-    return g.QWeight(spec.type, dst, spec.M, spec.K)
+    rows = spec.M * getattr(spec, "n_expert", 1)
+    nbytes = rows * nb * bs
+    dst = torch.empty(nbytes + 64, dtype=torch.uint8, device=device)
+    step = max(1, (1 << 28) // (nb * bs))                      # generate in slabs of <= 256 MiB
+    for r0 in range(0, rows, step):
+        r1 = min(rows, r0 + step)
+        raw = torch.randint(0, 256, (r1 - r0, nb, bs), dtype=torch.uint8, device=device)
+        for off in {g.Q4_K: (0, 2), g.Q5_K: (0, 2), g.Q6_K: (208,), g.Q8_0: (0,)}[spec.type]:
+            sc = (torch.rand((r1 - r0, nb), device=device) * 0.02 + 1e-3).to(torch.float16)
+            raw[:, :, off:off + 2] = sc.view(torch.uint8).view(r1 - r0, nb, 2)
+        rc = g.lib().mi355q_weights_pack_d2d(spec.type, dst.data_ptr() + r0 * nb * bs, raw.data_ptr(), r1 - r0, spec.K,
+                                             int(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(g.lib().mi355q_last_error().decode())
+        torch.cuda.synchronize()
+        del raw
+    return g.QWeight(spec.type, dst, spec.M, spec.K, getattr(spec, "n_expert", 1))
 
 
 class Stage:
@@ -77,39 +86,60 @@ class Stage:
 
     def __init__(self, torch, g, specs, fuse, device):
         self.torch, self.g = torch, g
-        self.groups = []         # (list[QWeight], x tensor, list[y tensors], nbytes)
+        self.groups = []         # (list[QWeight], x tensor, list[y tensors], bytes a token reads, ids tensor or None)
         self.bytes = 0
+        self.has_moe = any(s.n_expert > 1 for s in specs)
         xs = {}
-        def x_for(k):
-            if k not in xs:
-                xs[k] = torch.randn((1, k), dtype=torch.float32, device=device)
-            return xs[k]
+        def x_for(k, rows=1):
+            if (k, rows) not in xs:
+                xs[(k, rows)] = torch.randn((1, k) if rows == 1 else (1, rows, k), dtype=torch.float32, device=device)
+            return xs[(k, rows)]
         by_layer = {}
         for s in specs:
             by_layer.setdefault(s.layer, []).append(s)
         for layer in sorted(by_layer, key=lambda l: (l < 0, l)):
             ss = {s.name.split(".")[-1]: s for s in by_layer[layer]}
-            plan = [["attn_q", "attn_k", "attn_v"], ["attn_output"], ["ffn_gate", "ffn_up"], ["ffn_down"]] if layer >= 0 else [["output"]]
+            if layer < 0:
+                plan = [["output"]]
+            elif "ffn_gate_exps" in ss:                        # MoE: every expert tensor is its own MUL_MAT_ID
+                plan = [["attn_q", "attn_k", "attn_v"], ["attn_output"], ["ffn_gate_exps"], ["ffn_up_exps"], ["ffn_down_exps"]]
+            else:
+                plan = [["attn_q", "attn_k", "attn_v"], ["attn_output"], ["ffn_gate", "ffn_up"], ["ffn_down"]]
             if not fuse:
                 plan = [[n] for grp in plan for n in grp]
             for grp in plan:
                 ws = [device_random_weight(torch, g, ss[n], device) for n in grp]
-                ys = [torch.empty((1, w.M), dtype=torch.float32, device=device) for w in ws]
-                nbytes = sum(w.nbytes for w in ws)
-                self.groups.append((ws, x_for(ws[0].K), ys, nbytes))
+                nbytes = sum(ss[n].nbytes for n in grp)
+                if ws[0].n_expert > 1:
+                    sp = ss[grp[0]]
+                    # ids: the experts the router picked for this token (fixed, distinct per layer); ffn_down gets one activation row per slot
+                    ids = torch.tensor([[(3 * max(layer, 0) + u) % sp.n_expert for u in range(sp.n_used)]], dtype=torch.int32, device=device)
+                    x = x_for(ws[0].K, sp.n_used if "down" in grp[0] else 1)
+                    if x.dim() == 2:
+                        x = x.view(1, 1, -1)
+                    self.groups.append((ws, x, None, nbytes, ids))
+                else:
+                    ys = [torch.empty((1, w.M), dtype=torch.float32, device=device) for w in ws]
+                    self.groups.append((ws, x_for(ws[0].K), ys, nbytes, None))
                 self.bytes += nbytes
 
     def make_plan(self):
         """The same steps as ONE persistent launch; every step after the first waits (grid barrier) for the previous one."""
-        return self.g.Plan([(ws, x, ys, i > 0) for i, (ws, x, ys, _) in enumerate(self.groups)])
+        return self.g.Plan([(ws, x, ys, i > 0) for i, (ws, x, ys, _, _) in enumerate(self.groups)])
+
+    def run_group(self, grp):
+        g = self.g
+        ws, x, ys, _, ids = grp
+        if ids is not None:
+            g.mul_mat_id(ws[0], x, ids)
+        elif len(ws) == 1:
+            g.mul_mat(ws[0], x, out=ys[0])
+        else:
+            g.mul_mat_multi(ws, x, outs=ys)
 
     def run(self):
-        g = self.g
-        for ws, x, ys, _ in self.groups:
-            if len(ws) == 1:
-                g.mul_mat(ws[0], x, out=ys[0])
-            else:
-                g.mul_mat_multi(ws, x, outs=ys)
+        for grp in self.groups:
+            self.run_group(grp)
 
 
 def measured_hbm_read_GBps(torch, device):
@@ -178,7 +208,7 @@ def main():
         if world > 1:
             dist.init_process_group("nccl", device_id=device)
 
-    cfg = wl.LLAMA3_8B
+    cfg = wl.MODELS[a.model]
     specs = wl.llama_matmuls(cfg, a.ftype)
     total_bytes = sum(s.nbytes for s in specs)
     ranges = wl.partition_layers(cfg["n_layer"], world)
@@ -196,6 +226,8 @@ def main():
     else:
         stage = Stage(torch, g, mine, not a.no_fuse, device)
         launch = "eager" if a.no_graph else a.launch
+        if stage.has_moe and launch == "plan":
+            launch = "graph"                                    # the decode plan covers MUL_MAT chains; MUL_MAT_ID runs per launch
         graph = plan = None
         stage.run(); torch.cuda.synchronize()                  # warm every kernel / attribute (and the reference outputs for the plan check)
         if launch == "graph":
@@ -203,15 +235,15 @@ def main():
             with torch.cuda.graph(graph):
                 stage.run()
         elif launch == "plan":
-            want = [[y.clone() for y in ys] for _, _, ys, _ in stage.groups]
+            want = [[y.clone() for y in ys] for _, _, ys, _, _ in stage.groups]
             plan = stage.make_plan()
-            for _, _, ys, _ in stage.groups:
+            for _, _, ys, _, _ in stage.groups:
                 for y in ys:
                     y.zero_()
             plan.run(); torch.cuda.synchronize()
             if plan.status() != 0:
                 raise RuntimeError("decode plan aborted (grid barrier timeout)")
-            for (_, _, ys, _), ws_ in zip(stage.groups, want):  # the persistent launch computes exactly what the per-matmul launches do
+            for (_, _, ys, _, _), ws_ in zip(stage.groups, want):  # the persistent launch computes exactly what the per-matmul launches do
                 for y, w_ in zip(ys, ws_):
                     if not torch.equal(y.view(torch.int32), w_.view(torch.int32)):
                         raise RuntimeError("decode plan output differs from the per-matmul launches")
@@ -246,15 +278,15 @@ def main():
         dt = float(tmax.item())
 
     out = {
-        "metric": "llama-bench tg128 tok/s (quantized-matmul hot path), Llama-3-8B " + a.ftype,
+        "metric": "llama-bench tg128 tok/s (quantized-matmul hot path), " + {"llama3-8b": "Llama-3-8B", "llama3-70b": "Llama-3-70B", "mixtral-8x7b": "Mixtral-8x7B"}[a.model] + " " + a.ftype,
         "value": round(a.steps / dt, 2), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int8",
         "data": "synthetic (random packed blocks with finite scales, gaussian activations)",
-        "config": {"workload": f"Llama-3-8B {a.ftype} tg (N=1): all {len(specs)} quantized mul_mat weights per token, "
+        "config": {"workload": f"{a.model} {a.ftype} tg (N=1): all {len(specs)} quantized mul_mat{'/mul_mat_id' if stage is not None and stage.has_moe else ''} weights per token, "
                                f"{total_bytes / 1e9:.3f} GB/token; {'fused q|k|v and gate|up steps, ' if not a.no_fuse else ''}"
                                + {"plan": "one persistent cooperative launch per token (grid barrier between dependent steps)",
-                                  "graph": "one launch per step, hipGraph replay", "eager": "one launch per step, eager"}["eager" if a.no_graph else a.launch]
+                                  "graph": "one launch per step, hipGraph replay", "eager": "one launch per step, eager"}[launch if not a.dry_run else "eager"]
                                + "; non-matmul graph ops not executed",
                    "bytes_per_token": total_bytes,
                    "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs (RCCL send/recv of the boundary activation)"},
@@ -273,14 +305,14 @@ def main():
         # (a) the per-matmul launch path: every launch is the same kernel template (k_gemv_fast); its instantiations are timed
         # per (weight type, K) class, the launches of a class captured back to back in their own hipGraph.
         classes = {}
-        for ws, x, ys, nbytes in stage.groups:
-            classes.setdefault((g.TYPE_NAMES[ws[0].type], ws[0].K), []).append((ws, x, ys, nbytes))
+        for grp in stage.groups:
+            ws = grp[0]
+            classes.setdefault((g.TYPE_NAMES[ws[0].type] + ("_id" if grp[4] is not None else ""), ws[0].K), []).append(grp)
         per_kernel = {}
         for (tname, kk), grp in classes.items():
             def run_class():
-                for ws, x, ys, _ in grp:
-                    if len(ws) == 1: g.mul_mat(ws[0], x, out=ys[0])
-                    else: g.mul_mat_multi(ws, x, outs=ys)
+                for gg in grp:
+                    stage.run_group(gg)
             run_class(); torch.cuda.synchronize()
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
@@ -322,7 +354,23 @@ def main():
                            "whole_token_GBps": round(total_bytes * a.steps / dt / 1e9, 1) if world == 1 else None,
                            "measured_hbm_read_peak_GBps": measured_hbm_read_GBps(torch, device),   # this box, plain streaming read (guide: ~6.3 TB/s)
                            "all_kernels": all_kernels}
-        if not a.no_cpu_baseline and world == 1:
+        # ---- pp512: the same weights at N = 512 on the MFMA tier (second half of the north-star metric) ----
+        if not a.no_pp and world == 1 and not stage.has_moe:
+            Npp = 512
+            xs_pp = {k: torch.randn((Npp, k), dtype=torch.float32, device=device) for k in {w.K for grp in stage.groups for w in grp[0]}}
+            ys_pp = {m: torch.empty((Npp, m), dtype=torch.float32, device=device) for m in {w.M for grp in stage.groups for w in grp[0]}}
+            def pp():
+                for grp in stage.groups:
+                    for w in grp[0]:
+                        g.mul_mat(w, xs_pp[w.K], out=ys_pp[w.M])
+            secs = timed(pp, 3)
+            flop = 2.0 * Npp * sum(w.M * w.K for grp in stage.groups for w in grp[0])
+            out["pp512"] = {"value": round(Npp / secs, 1), "unit": "tok/s", "ms": round(1e3 * secs, 3), "TFLOPs": round(flop / secs / 1e12, 1),
+                            "roofline": {"bound": "mfma", "achieved": round(flop / secs / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                         "frac": round(flop / secs / 1e12 / 2500.0, 4), "kernel": "k_mmq_bf16 (bf16 MFMA 16x16x32, f32 accumulate)"},
+                            "note": "all quantized matmuls of the model at N = 512, one launch each; operands bf16 (weights dequantized in f32 first)"}
+            del xs_pp, ys_pp
+        if not a.no_cpu_baseline and world == 1 and a.model == "llama3-8b":      # (the headline config; the reference chain has no MUL_MAT_ID leg)
             try:
                 out["cpu_baseline"] = cpu_baseline(specs, a.cpu_seconds)
             except Exception as e:                              # the baseline is a report, never a reason to fail the bench

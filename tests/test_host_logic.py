@@ -51,3 +51,20 @@ def test_two_rank_hop_protocol_gloo(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "strong"
     assert out["unit"] == "tok/s" and out["value"] > 0
     assert "layer split over 2 GPUs" in out["config"]["parallelism"]
+
+
+def test_other_model_recipes():
+    """Q4_K_M type recipes of the other BASELINE.json configs (src/llama-quant.cpp:235-322) and what a token reads."""
+    from ggml_mi355 import workloads as wl, Q4_K, Q5_K, Q6_K, Q8_0
+    s70 = wl.llama_matmuls(wl.LLAMA3_70B, "Q4_K_M")
+    assert len(s70) == 80 * 7 + 1
+    v = [s for s in s70 if s.name.endswith("attn_v")]
+    assert {s.type for s in v} == {Q5_K, Q6_K}                       # 70B: attn_v never stays Q4_K
+    assert sum(s.type == Q6_K for s in v) == sum(wl.use_more_bits(i, 80) for i in range(80))
+    assert 41.5e9 < sum(s.nbytes for s in s70) < 42.5e9
+    mx = wl.llama_matmuls(wl.MIXTRAL_8X7B, "Q4_K_M")
+    by = {s.name.split(".")[-1]: s for s in mx if s.layer == 0}
+    assert by["attn_k"].type == Q8_0 and by["attn_v"].type == Q8_0 and by["attn_output"].type == Q5_K and by["attn_q"].type == Q4_K
+    assert by["ffn_gate_exps"].n_expert == 8 and by["ffn_gate_exps"].n_used == 2 and by["ffn_down_exps"].type == Q6_K
+    assert by["ffn_up_exps"].stored_bytes == 4 * by["ffn_up_exps"].nbytes      # a token reads 2 of 8 experts
+    assert 28.0e9 < sum(s.stored_bytes for s in mx) < 28.8e9 and 7.8e9 < sum(s.nbytes for s in mx) < 8.0e9
