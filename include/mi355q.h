@@ -199,6 +199,39 @@ int64_t mi355q_plan_weight_bytes(const mi355q_plan *plan);
 int     mi355q_plan_launch_stages(const mi355q_plan *plan);
 int     mi355q_plan_destroy(mi355q_plan *plan);
 
+/* ---- residency ops: the small f32/f16 graph ops between the quantized matmuls of a decode graph ------
+ * Tensors are described the ggml way: ne[] elements per dimension, nb[] strides in BYTES (views, permutes and broadcasts
+ * are expressed through them), data = device pointer.  type: MI355Q_T_F32 / MI355Q_T_F16.  Each function is the device
+ * counterpart of one ggml CPU op and follows its arithmetic (cited in csrc/ops_glue.hip):
+ *   op_bin_bcast  GGML_OP_ADD/SUB/MUL/DIV   dst = a (op) b, b broadcast over a (ne_a % ne_b == 0), dst has a's shape
+ *   op_unary      GGML_OP_UNARY             SILU, RELU, SIGMOID, TANH, NEG, ABS
+ *   op_rms_norm   GGML_OP_RMS_NORM          per row: x / sqrt(mean(x^2) + eps), f32, rows contiguous
+ *   op_cpy        GGML_OP_CPY/CONT/DUP      logical element order, any strides, f32 <-> f16
+ *   op_soft_max   GGML_OP_SOFT_MAX          softmax(a*scale + slope*mask) per row; mask f32/f16 [ne00, >= ne01] or NULL      */
+#define MI355Q_T_F32 0
+#define MI355Q_T_F16 1
+typedef struct mi355q_tensor {
+    void   *data;
+    int     type;
+    int64_t ne[4];
+    int64_t nb[4];
+} mi355q_tensor;
+#define MI355Q_OP_ADD 1
+#define MI355Q_OP_SUB 2
+#define MI355Q_OP_MUL 3
+#define MI355Q_OP_DIV 4
+#define MI355Q_UNARY_SILU    1
+#define MI355Q_UNARY_RELU    2
+#define MI355Q_UNARY_SIGMOID 3
+#define MI355Q_UNARY_TANH    4
+#define MI355Q_UNARY_NEG     5
+#define MI355Q_UNARY_ABS     6
+int mi355q_op_bin_bcast(int op, const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);
+int mi355q_op_unary(int uop, const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
+int mi355q_op_rms_norm(const mi355q_tensor *a, const mi355q_tensor *dst, float eps, void *stream);
+int mi355q_op_cpy(const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
+int mi355q_op_soft_max(const mi355q_tensor *a, const mi355q_tensor *mask, const mi355q_tensor *dst, float scale, float max_bias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

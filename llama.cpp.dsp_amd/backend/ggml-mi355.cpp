@@ -262,6 +262,57 @@ static void mi355_backend_synchronize(ggml_backend_t backend) {
     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
 }
 
+// ---- residency ops: thin wrappers over mi355q_op_* -- the tensor descriptor is ggml's ne[] / nb[] verbatim
+static mi355q_tensor mi355_td(const struct ggml_tensor * t) {
+    mi355q_tensor d;
+    d.data = t->data; d.type = t->type == GGML_TYPE_F16 ? MI355Q_T_F16 : MI355Q_T_F32;
+    for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t) t->nb[i]; }
+    return d;
+}
+static bool mi355_f32_or_f16(enum ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+
+static int mi355_unary_code(enum ggml_unary_op u) {
+    switch (u) {
+    case GGML_UNARY_OP_SILU: return MI355Q_UNARY_SILU;   case GGML_UNARY_OP_RELU: return MI355Q_UNARY_RELU;
+    case GGML_UNARY_OP_SIGMOID: return MI355Q_UNARY_SIGMOID; case GGML_UNARY_OP_TANH: return MI355Q_UNARY_TANH;
+    case GGML_UNARY_OP_NEG: return MI355Q_UNARY_NEG;     case GGML_UNARY_OP_ABS: return MI355Q_UNARY_ABS;
+    default: return 0;
+    }
+}
+
+static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
+    const mi355q_tensor d = mi355_td(dst);
+    const mi355q_tensor a = mi355_td(dst->src[0]);
+    switch (dst->op) {
+    case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: {
+        const mi355q_tensor b = mi355_td(dst->src[1]);
+        const int op = dst->op == GGML_OP_ADD ? MI355Q_OP_ADD : dst->op == GGML_OP_SUB ? MI355Q_OP_SUB : dst->op == GGML_OP_MUL ? MI355Q_OP_MUL : MI355Q_OP_DIV;
+        MQ_CHECK(mi355q_op_bin_bcast(op, &a, &b, &d, ctx->stream));
+    } break;
+    case GGML_OP_UNARY:
+        MQ_CHECK(mi355q_op_unary(mi355_unary_code(ggml_get_unary_op(dst)), &a, &d, ctx->stream));
+        break;
+    case GGML_OP_RMS_NORM: {
+        float eps; memcpy(&eps, dst->op_params, sizeof(float));
+        MQ_CHECK(mi355q_op_rms_norm(&a, &d, eps, ctx->stream));
+    } break;
+    case GGML_OP_CPY: {                                       // dst = src[1] viewed; data goes src[0] -> dst (ggml.c ggml_cpy_impl)
+        MQ_CHECK(mi355q_op_cpy(&a, &d, ctx->stream));
+    } break;
+    case GGML_OP_CONT: case GGML_OP_DUP:
+        MQ_CHECK(mi355q_op_cpy(&a, &d, ctx->stream));
+        break;
+    case GGML_OP_SOFT_MAX: {
+        float scale, max_bias;
+        memcpy(&scale, (const float *) dst->op_params + 0, sizeof(float));
+        memcpy(&max_bias, (const float *) dst->op_params + 1, sizeof(float));
+        if (dst->src[1]) { const mi355q_tensor m = mi355_td(dst->src[1]); MQ_CHECK(mi355q_op_soft_max(&a, &m, &d, scale, max_bias, ctx->stream)); }
+        else MQ_CHECK(mi355q_op_soft_max(&a, nullptr, &d, scale, max_bias, ctx->stream));
+    } break;
+    default: GGML_ABORT("mi355_glue_op: unexpected op");
+    }
+}
+
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
@@ -273,6 +324,9 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
             break;
         case GGML_OP_MUL_MAT:    mi355_mul_mat(ctx, node);    break;
         case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_UNARY: case GGML_OP_RMS_NORM:
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX:
+            mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
             return GGML_STATUS_FAILED;
@@ -375,6 +429,33 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
         if (!ggml_is_contiguous(a) || a->view_src) return false;
         if (b->nb[0] != sizeof(float) || !ggml_is_contiguous(op) || ids->nb[0] != sizeof(int32_t)) return false;
         if (ids->ne[0] * ids->ne[1] > 65535) return false;
+        return true;
+    }
+    // ---- residency ops: f32 (CPY/CONT/DUP also f16), operands in our buffers
+    case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: {
+        const struct ggml_tensor * a = op->src[0];
+        const struct ggml_tensor * b = op->src[1];
+        if (a->type != GGML_TYPE_F32 || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+        return mi355_operand_ok(a) && mi355_operand_ok(b) && ggml_are_same_shape(a, op) && ggml_can_repeat(b, a);
+    }
+    case GGML_OP_UNARY: {
+        const struct ggml_tensor * a = op->src[0];
+        if (a->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !mi355_operand_ok(a)) return false;
+        return mi355_unary_code(ggml_get_unary_op(op)) != 0;
+    }
+    case GGML_OP_RMS_NORM: {
+        const struct ggml_tensor * a = op->src[0];
+        return a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && mi355_operand_ok(a) && a->nb[0] == sizeof(float) && op->nb[0] == sizeof(float);
+    }
+    case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
+        const struct ggml_tensor * a = op->src[0];
+        return mi355_f32_or_f16(a->type) && mi355_f32_or_f16(op->type) && mi355_operand_ok(a) && ggml_nelements(a) == ggml_nelements(op);
+    }
+    case GGML_OP_SOFT_MAX: {
+        const struct ggml_tensor * a = op->src[0];
+        const struct ggml_tensor * m = op->src[1];
+        if (a->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !mi355_operand_ok(a) || !ggml_is_contiguous(a) || !ggml_is_contiguous(op)) return false;
+        if (m && (!mi355_f32_or_f16(m->type) || !mi355_operand_ok(m) || !ggml_is_contiguous(m) || m->ne[0] != a->ne[0] || m->ne[1] < a->ne[1])) return false;
         return true;
     }
     default:

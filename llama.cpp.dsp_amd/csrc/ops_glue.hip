@@ -1,0 +1,226 @@
+// ops_glue.hip -- the small f32/f16 graph ops that sit between the quantized matmuls of a decode graph (SURVEY.md 8f-1:
+// the "residency" set).  Without them every layer is ~10 scheduler splits with PCIe round trips; with them a layer's
+// activations never leave HBM.  None of these is a roofline path at decode sizes (KBs per op): they are written for
+// generality (ggml's strides, broadcasting and views) and exactness against the reference CPU ops, not for speed --
+// the fused forms belong in the decode plan.
+//
+//   ADD / SUB / MUL / DIV   ggml_compute_forward_{add,sub,mul,div}_f32 (binary_op), ggml-cpu/binary-ops.cpp  [broadcast of src1]
+//   UNARY(SILU, ...)        ggml-cpu/unary-ops.cpp, vec.h:ggml_silu_f32 = x / (1 + expf(-x))
+//   RMS_NORM                ggml-cpu/ops.cpp:3180-3226 (sum of squares accumulated in double, scale = 1/sqrtf(mean + eps))
+//   CPY / CONT / DUP        ggml-cpu/ops.cpp ggml_compute_forward_dup (logical element order), f32 <-> f16
+//   SOFT_MAX                ggml-cpu/ops.cpp:4641-4736 (scale, mask f32/f16 broadcast over rows, ALiBi slope, max-subtracted exp)
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "mi355q_common.h"
+
+namespace mi355q {
+
+struct TensorD { char * data; int type; int64_t ne[4]; int64_t nb[4]; };     // device copy of mi355q_tensor (type: 0 f32, 1 f16)
+
+static TensorD to_d(const mi355q_tensor * t) {
+    TensorD d; d.data = (char *) t->data; d.type = t->type;
+    for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; }
+    return d;
+}
+static int64_t nelements(const mi355q_tensor * t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+static bool same_shape(const mi355q_tensor * a, const mi355q_tensor * b) {
+    return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3];
+}
+
+__device__ __forceinline__ float ld_elem(const char * p, int type) {
+    return type == 0 ? *(const float *) p : __half2float(*(const __half *) p);
+}
+__device__ __forceinline__ void st_elem(char * p, int type, float v) {
+    if (type == 0) *(float *) p = v; else *(__half *) p = __float2half_rn(v);
+}
+
+// ---- binary ops with ggml broadcasting: dst[i] = a[i] (op) b[i % ne_b] ------------------------------
+enum { BIN_ADD = MI355Q_OP_ADD, BIN_SUB = MI355Q_OP_SUB, BIN_MUL = MI355Q_OP_MUL, BIN_DIV = MI355Q_OP_DIV };
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_bin_bcast(const TensorD a, const TensorD b, const TensorD d, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0], i1 = r % d.ne[1], r2 = r / d.ne[1], i2 = r2 % d.ne[2], i3 = r2 / d.ne[2];
+        const float x = ld_elem(a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3], a.type);
+        const float y = ld_elem(b.data + (i0 % b.ne[0]) * b.nb[0] + (i1 % b.ne[1]) * b.nb[1] + (i2 % b.ne[2]) * b.nb[2] + (i3 % b.ne[3]) * b.nb[3], b.type);
+        float v;
+        if constexpr (OP == BIN_ADD) v = __fadd_rn(x, y);
+        else if constexpr (OP == BIN_SUB) v = __fsub_rn(x, y);
+        else if constexpr (OP == BIN_MUL) v = __fmul_rn(x, y);
+        else v = __fdiv_rn(x, y);
+        st_elem(d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3], d.type, v);
+    }
+}
+
+// ---- unary ops -------------------------------------------------------------------------------------
+template <int OP>
+__global__ void __launch_bounds__(256) k_unary(const TensorD a, const TensorD d, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0], i1 = r % d.ne[1], r2 = r / d.ne[1], i2 = r2 % d.ne[2], i3 = r2 / d.ne[2];
+        const float x = ld_elem(a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3], a.type);
+        float v;
+        if constexpr (OP == MI355Q_UNARY_SILU)         v = __fdiv_rn(x, 1.0f + expf(-x));
+        else if constexpr (OP == MI355Q_UNARY_RELU)    v = x > 0.0f ? x : 0.0f;
+        else if constexpr (OP == MI355Q_UNARY_SIGMOID) v = __fdiv_rn(1.0f, 1.0f + expf(-x));
+        else if constexpr (OP == MI355Q_UNARY_TANH)    v = tanhf(x);
+        else if constexpr (OP == MI355Q_UNARY_NEG)     v = -x;
+        else                                           v = fabsf(x);
+        st_elem(d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3], d.type, v);
+    }
+}
+
+// ---- reductions over a wave in double (the CPU accumulates in double too) -----------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- RMS_NORM: one wave per row -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rms_norm(const TensorD a, const TensorD d, float eps, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t i1 = row % a.ne[1], r2 = row / a.ne[1], i2 = r2 % a.ne[2], i3 = r2 / a.ne[2];
+    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int64_t n = a.ne[0];
+    double s = 0.0;
+    for (int64_t i = lane; i < n; i += 64) s += (double) __fmul_rn(x[i], x[i]);       // (ggml_float)(x*x): the square is rounded to f32 first
+    s = wave_sum_f64(s);
+    const float mean = (float) (s / (double) n);
+    const float scale = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, eps)));
+    for (int64_t i = lane; i < n; i += 64) y[i] = __fmul_rn(x[i], scale);
+}
+
+// ---- CPY / CONT / DUP: logical element order, any strides, f32 <-> f16 -------------------------------------
+__global__ void __launch_bounds__(256) k_cpy(const TensorD a, const TensorD d, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t a0 = i % a.ne[0], ar = i / a.ne[0], a1 = ar % a.ne[1], ar2 = ar / a.ne[1], a2 = ar2 % a.ne[2], a3 = ar2 / a.ne[2];
+        const int64_t d0 = i % d.ne[0], dr = i / d.ne[0], d1 = dr % d.ne[1], dr2 = dr / d.ne[1], d2 = dr2 % d.ne[2], d3 = dr2 / d.ne[2];
+        const char * src = a.data + a0 * a.nb[0] + a1 * a.nb[1] + a2 * a.nb[2] + a3 * a.nb[3];
+        char * dst = d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3];
+        if (a.type == d.type) { if (a.type == 0) *(float *) dst = *(const float *) src; else *(uint16_t *) dst = *(const uint16_t *) src; }
+        else st_elem(dst, d.type, ld_elem(src, a.type));
+    }
+}
+
+// ---- SOFT_MAX: one wave per row; mask (f32/f16) broadcast over rows i1 % ne01; ALiBi slope per head -------------
+__global__ void __launch_bounds__(256) k_soft_max(const TensorD a, const TensorD m, const TensorD d, float scale, float max_bias,
+                                                  float m0, float m1, uint32_t n_head_log2, int64_t nrows, int has_mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t nc = a.ne[0];
+    const float * sp = (const float *) (a.data + row * a.nb[1]);
+    float * dp = (float *) (d.data + row * d.nb[1]);
+    const uint32_t h = (uint32_t) ((row / a.ne[1]) % a.ne[2]);
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const char * mp = has_mask ? m.data + (row % a.ne[1]) * nc * (m.type == 0 ? 4 : 2) : nullptr;
+    auto val = [&](int64_t i) {
+        float v = __fmul_rn(sp[i], scale);
+        if (mp) v = __fadd_rn(v, __fmul_rn(slope, m.type == 0 ? ((const float *) mp)[i] : __half2float(((const __half *) mp)[i])));
+        return v;
+    };
+    float mx = -INFINITY;
+    for (int64_t i = lane; i < nc; i += 64) mx = fmaxf(mx, val(i));
+    mx = wave_max_f32(mx);
+    double sum = 0.0;
+    for (int64_t i = lane; i < nc; i += 64) {
+        const float e = expf(__fsub_rn(val(i), mx));
+        dp[i] = e;
+        sum += (double) e;
+    }
+    sum = wave_sum_f64(sum);
+    const float inv = (float) (1.0 / sum);
+    for (int64_t i = lane; i < nc; i += 64) dp[i] = __fmul_rn(dp[i], inv);
+}
+
+static int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
+
+} // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" {
+
+void mi355q_set_error(const char * msg);          // api.hip
+
+#define OPS_FAIL(code, msg) do { mi355q_set_error(msg); return code; } while (0)
+#define OPS_LAUNCHED() return hipGetLastError() == hipSuccess ? MI355Q_OK : (mi355q_set_error("kernel launch failed"), MI355Q_ERR_HIP)
+
+int mi355q_op_bin_bcast(int op, const mi355q_tensor * a, const mi355q_tensor * b, const mi355q_tensor * dst, void * stream) {
+    if (!a || !b || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_bin_bcast: null tensor");
+    if (!same_shape(a, dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_bin_bcast: dst must have the shape of src0");
+    for (int i = 0; i < 4; ++i) if (b->ne[i] <= 0 || a->ne[i] % b->ne[i]) OPS_FAIL(MI355Q_ERR_SHAPE, "op_bin_bcast: src1 does not broadcast over src0");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    const dim3 g(grid_for(n)), t(256);
+    switch (op) {
+    case MI355Q_OP_ADD: hipLaunchKernelGGL(k_bin_bcast<BIN_ADD>, g, t, 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n); break;
+    case MI355Q_OP_SUB: hipLaunchKernelGGL(k_bin_bcast<BIN_SUB>, g, t, 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n); break;
+    case MI355Q_OP_MUL: hipLaunchKernelGGL(k_bin_bcast<BIN_MUL>, g, t, 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n); break;
+    case MI355Q_OP_DIV: hipLaunchKernelGGL(k_bin_bcast<BIN_DIV>, g, t, 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n); break;
+    default: OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_bin_bcast: unknown op");
+    }
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_unary(int uop, const mi355q_tensor * a, const mi355q_tensor * dst, void * stream) {
+    if (!a || !dst || !same_shape(a, dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_unary: shapes differ");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    const dim3 g(grid_for(n)), t(256);
+#define U(OPV) case OPV: hipLaunchKernelGGL(k_unary<OPV>, g, t, 0, (hipStream_t) stream, to_d(a), to_d(dst), n); break;
+    switch (uop) {
+    U(MI355Q_UNARY_SILU) U(MI355Q_UNARY_RELU) U(MI355Q_UNARY_SIGMOID) U(MI355Q_UNARY_TANH) U(MI355Q_UNARY_NEG) U(MI355Q_UNARY_ABS)
+    default: OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_unary: unknown op");
+    }
+#undef U
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_rms_norm(const mi355q_tensor * a, const mi355q_tensor * dst, float eps, void * stream) {
+    if (!a || !dst || !same_shape(a, dst) || a->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_rms_norm: f32 tensors of one shape");
+    if (a->nb[0] != 4 || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_rms_norm: rows must be contiguous");
+    const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
+    if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_rms_norm, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), eps, nrows);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * stream) {
+    if (!a || !dst || nelements(a) != nelements(dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_cpy: element counts differ");
+    if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 / f16 only");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_soft_max(const mi355q_tensor * a, const mi355q_tensor * mask, const mi355q_tensor * dst, float scale, float max_bias, void * stream) {
+    if (!a || !dst || !same_shape(a, dst) || a->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_soft_max: f32 tensors of one shape");
+    // rows dense and equally spaced (the reference asserts contiguity of dst and walks src0 rows by nb[1])
+    if (a->nb[0] != 4 || dst->nb[0] != 4 || a->nb[2] != a->nb[1] * a->ne[1] || a->nb[3] != a->nb[2] * a->ne[2] ||
+        dst->nb[1] != dst->ne[0] * 4 || dst->nb[2] != dst->nb[1] * dst->ne[1] || dst->nb[3] != dst->nb[2] * dst->ne[2])
+        OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_soft_max: rows must be equally spaced");
+    if (mask && (mask->ne[0] != a->ne[0] || mask->ne[1] < a->ne[1] || mask->nb[0] != (mask->type == 0 ? 4 : 2) ||
+                 mask->nb[1] != mask->ne[0] * mask->nb[0])) OPS_FAIL(MI355Q_ERR_SHAPE, "op_soft_max: mask must be contiguous [ne00, >= ne01]");
+    const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
+    if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
+    const uint32_t n_head = (uint32_t) a->ne[2];
+    uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= n_head) n_head_log2 *= 2;
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    TensorD md = mask ? to_d(mask) : to_d(a);
+    hipLaunchKernelGGL(k_soft_max, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias,
+                       m0, m1, n_head_log2, nrows, mask ? 1 : 0);
+    OPS_LAUNCHED();
+}
+
+} // extern "C"

@@ -53,6 +53,7 @@ ABI_SYMBOLS = [
     "mi355q_mul_mat_id_workspace", "mi355q_mul_mat_id",
     "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
     "mi355q_plan_destroy",
+    "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
 ]
 
 
@@ -70,6 +71,14 @@ class _Stage(C.Structure):
 
 
 STAGE_DEPENDS = 0x1
+
+
+class _Tensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("type", C.c_int), ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4)]
+
+
+OP_ADD, OP_SUB, OP_MUL, OP_DIV = 1, 2, 3, 4
+UNARY_SILU, UNARY_RELU, UNARY_SIGMOID, UNARY_TANH, UNARY_NEG, UNARY_ABS = 1, 2, 3, 4, 5, 6
 
 _lib = None
 
@@ -106,6 +115,12 @@ def lib() -> C.CDLL:
     L.mi355q_plan_destroy.argtypes = [vp]
     L.mi355q_plan_weight_bytes.restype = i64; L.mi355q_plan_weight_bytes.argtypes = [vp]
     L.mi355q_plan_launch_stages.argtypes = [vp]
+    TP = C.POINTER(_Tensor)
+    L.mi355q_op_bin_bcast.argtypes = [i32, TP, TP, TP, vp]
+    L.mi355q_op_unary.argtypes = [i32, TP, TP, vp]
+    L.mi355q_op_rms_norm.argtypes = [TP, TP, C.c_float, vp]
+    L.mi355q_op_cpy.argtypes = [TP, TP, vp]
+    L.mi355q_op_soft_max.argtypes = [TP, TP, TP, C.c_float, C.c_float, vp]
     L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64]
     L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     _lib = L
@@ -280,6 +295,57 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def _td(t) -> _Tensor:
+    """torch tensor (f32/f16, <= 4 dims, torch dims are ggml dims reversed) -> mi355q_tensor with ggml-ordered ne/nb."""
+    torch = _torch()
+    assert t.dtype in (torch.float32, torch.float16) and 1 <= t.dim() <= 4
+    shape = list(t.shape)[::-1] + [1] * (4 - t.dim())
+    es = t.element_size()
+    strides = [s * es for s in list(t.stride())[::-1]]
+    nb = strides + [0] * (4 - t.dim())
+    for i in range(t.dim(), 4):                       # ggml convention for the padded dims: nb[i] = nb[i-1] * ne[i-1]
+        nb[i] = nb[i - 1] * shape[i - 1]
+    d = _Tensor(); d.data = t.data_ptr(); d.type = 0 if t.dtype == torch.float32 else 1
+    for i in range(4):
+        d.ne[i] = shape[i]; d.nb[i] = nb[i]
+    return d
+
+
+def op_bin_bcast(op: int, a, b, out=None):
+    """GGML_OP_ADD/SUB/MUL/DIV: out = a (op) b with ggml broadcasting of b over a (shapes given torch-style)."""
+    torch = _torch()
+    out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
+    _check(lib().mi355q_op_bin_bcast(op, C.byref(_td(a)), C.byref(_td(b)), C.byref(_td(out)), _stream(torch)), "op_bin_bcast")
+    return out
+
+
+def op_unary(uop: int, a, out=None):
+    torch = _torch()
+    out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
+    _check(lib().mi355q_op_unary(uop, C.byref(_td(a)), C.byref(_td(out)), _stream(torch)), "op_unary")
+    return out
+
+
+def op_rms_norm(a, eps: float, out=None):
+    torch = _torch()
+    out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
+    _check(lib().mi355q_op_rms_norm(C.byref(_td(a)), C.byref(_td(out)), eps, _stream(torch)), "op_rms_norm")
+    return out
+
+
+def op_cpy(a, out):
+    _check(lib().mi355q_op_cpy(C.byref(_td(a)), C.byref(_td(out)), _stream(_torch())), "op_cpy")
+    return out
+
+
+def op_soft_max(a, mask=None, scale: float = 1.0, max_bias: float = 0.0, out=None):
+    torch = _torch()
+    out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
+    _check(lib().mi355q_op_soft_max(C.byref(_td(a)), C.byref(_td(mask)) if mask is not None else None, C.byref(_td(out)), scale, max_bias,
+                                    _stream(torch)), "op_soft_max")
+    return out
 
 
 def mul_mat_id(w: QWeight, x, ids, flags: int = 0):

@@ -74,3 +74,22 @@ def test_reference_test_backend_ops(op):
               "iq2_xxs", "iq2_xs", "iq2_s", "iq3_xxs", "iq3_s", "iq1_s", "iq1_m"):
         mine = [l for l in cases if f"type_a={t}," in l and "type_b=f32" in l]
         assert mine and all("OK" in l for l in mine if "per=[0,1,2,3]" in l and "v=0" in l), t
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("op", ["ADD", "SUB", "MUL", "DIV", "RMS_NORM", "SILU", "RELU", "SIGMOID", "TANH", "NEG", "ABS",
+                                "CPY", "CONT", "DUP", "SOFT_MAX"])
+def test_reference_test_backend_ops_residency(op):
+    """The residency ops through the reference's own harness: every case the plugin accepts must pass the
+    harness' NMSE check against the ggml CPU backend; cases it declines are reported 'not supported' (never FAIL)."""
+    r = _run(["test", "-b", "MI355_0", "-o", op])
+    tail = r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+)/(\d+) tests passed", r.stdout)
+    assert m and m.group(1) == m.group(2), tail
+    assert "FAIL" not in r.stdout
+    cases = [l for l in r.stdout.splitlines() if l.lstrip().startswith(op + "(")]
+    ran = [l for l in cases if "OK" in l]
+    print(f"{op}: {len(ran)} of {len(cases)} cases ran on MI355_0 and passed")
+    assert len(ran) >= 1, tail
