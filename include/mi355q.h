@@ -207,7 +207,11 @@ int     mi355q_plan_destroy(mi355q_plan *plan);
  *   op_unary      GGML_OP_UNARY             SILU, RELU, SIGMOID, TANH, NEG, ABS
  *   op_rms_norm   GGML_OP_RMS_NORM          per row: x / sqrt(mean(x^2) + eps), f32, rows contiguous
  *   op_cpy        GGML_OP_CPY/CONT/DUP      logical element order, any strides, f32 <-> f16
- *   op_soft_max   GGML_OP_SOFT_MAX          softmax(a*scale + slope*mask) per row; mask f32/f16 [ne00, >= ne01] or NULL      */
+ *   op_soft_max   GGML_OP_SOFT_MAX          softmax(a*scale + slope*mask) per row; mask f32/f16 [ne00, >= ne01] or NULL
+ *   op_rope       GGML_OP_ROPE              normal (mode 0) and neox (mode 2) rotary embedding, YaRN parameters, optional
+ *                                           frequency factors (src2); pos = i32 device [ne2]
+ *   op_mul_mat_f  GGML_OP_MUL_MAT           with an f16 or f32 src0 (attention KQ / KQV): dst[m,n] = sum_k a[k,m] b[k,n],
+ *                                           dims 2/3 of src0 broadcast; an f16 src0 rounds src1 to f16 as the CPU does          */
 #define MI355Q_T_F32 0
 #define MI355Q_T_F16 1
 typedef struct mi355q_tensor {
@@ -231,6 +235,13 @@ int mi355q_op_unary(int uop, const mi355q_tensor *a, const mi355q_tensor *dst, v
 int mi355q_op_rms_norm(const mi355q_tensor *a, const mi355q_tensor *dst, float eps, void *stream);
 int mi355q_op_cpy(const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
 int mi355q_op_soft_max(const mi355q_tensor *a, const mi355q_tensor *mask, const mi355q_tensor *dst, float scale, float max_bias, void *stream);
+typedef struct mi355q_rope_params {      /* the op_params of GGML_OP_ROPE (ggml.c ggml_rope_impl) */
+    int   n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} mi355q_rope_params;
+int mi355q_op_rope(const mi355q_tensor *a, const int32_t *pos, const float *freq_factors, const mi355q_tensor *dst,
+                   const mi355q_rope_params *p, void *stream);
+int mi355q_op_mul_mat_f(const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);
 
 #ifdef __cplusplus
 }

@@ -309,6 +309,18 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
         if (dst->src[1]) { const mi355q_tensor m = mi355_td(dst->src[1]); MQ_CHECK(mi355q_op_soft_max(&a, &m, &d, scale, max_bias, ctx->stream)); }
         else MQ_CHECK(mi355q_op_soft_max(&a, nullptr, &d, scale, max_bias, ctx->stream));
     } break;
+    case GGML_OP_ROPE: {
+        mi355q_rope_params p;
+        const int32_t * q = (const int32_t *) dst->op_params;
+        p.n_dims = q[1]; p.mode = q[2]; p.n_ctx_orig = q[4];
+        memcpy(&p.freq_base, q + 5, 4); memcpy(&p.freq_scale, q + 6, 4); memcpy(&p.ext_factor, q + 7, 4);
+        memcpy(&p.attn_factor, q + 8, 4); memcpy(&p.beta_fast, q + 9, 4); memcpy(&p.beta_slow, q + 10, 4);
+        MQ_CHECK(mi355q_op_rope(&a, (const int32_t *) dst->src[1]->data, dst->src[2] ? (const float *) dst->src[2]->data : nullptr, &d, &p, ctx->stream));
+    } break;
+    case GGML_OP_MUL_MAT: {                                   // f16 / f32 src0 (the quantized types go through mi355_mul_mat)
+        const mi355q_tensor b = mi355_td(dst->src[1]);
+        MQ_CHECK(mi355q_op_mul_mat_f(&a, &b, &d, ctx->stream));
+    } break;
     default: GGML_ABORT("mi355_glue_op: unexpected op");
     }
 }
@@ -322,10 +334,12 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
         switch (node->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             break;
-        case GGML_OP_MUL_MAT:    mi355_mul_mat(ctx, node);    break;
+        case GGML_OP_MUL_MAT:
+            if (mi355_is_quant(node->src[0]->type)) mi355_mul_mat(ctx, node); else mi355_glue_op(ctx, node);
+            break;
         case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
         case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_UNARY: case GGML_OP_RMS_NORM:
-        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX:
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE:
             mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
@@ -408,6 +422,10 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
     case GGML_OP_MUL_MAT: {
         const struct ggml_tensor * a = op->src[0];
         const struct ggml_tensor * b = op->src[1];
+        if (mi355_f32_or_f16(a->type)) {                          // attention KQ / KQV: k contiguous in both operands, any other strides
+            if (b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !mi355_operand_ok(a) || !mi355_operand_ok(b)) return false;
+            return a->nb[0] == ggml_type_size(a->type) && b->nb[0] == sizeof(float) && (op->ne[0] * op->ne[1] * op->ne[2] * op->ne[3] + 3) / 4 <= 0x7FFFFFFF;
+        }
         if (!mi355_is_quant(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
         if (!mi355_operand_ok(a)) return false;
         // src0: whole rows of its root tensor, rows dense, 16-byte aligned row pitch where the rows are planar
@@ -450,6 +468,14 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
     case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
         const struct ggml_tensor * a = op->src[0];
         return mi355_f32_or_f16(a->type) && mi355_f32_or_f16(op->type) && mi355_operand_ok(a) && ggml_nelements(a) == ggml_nelements(op);
+    }
+    case GGML_OP_ROPE: {
+        const struct ggml_tensor * a = op->src[0];
+        const int mode = ((const int32_t *) op->op_params)[2];
+        if (a->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !mi355_operand_ok(a) || a->nb[0] != sizeof(float) || op->nb[0] != sizeof(float)) return false;
+        if (mode != 0 && mode != 2) return false;                 // normal and neox; mrope / vision stay on the CPU
+        if (op->src[2] && op->src[2]->type != GGML_TYPE_F32) return false;
+        return a->ne[0] % 2 == 0;
     }
     case GGML_OP_SOFT_MAX: {
         const struct ggml_tensor * a = op->src[0];

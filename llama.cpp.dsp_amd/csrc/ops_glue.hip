@@ -9,6 +9,8 @@
 //   RMS_NORM                ggml-cpu/ops.cpp:3180-3226 (sum of squares accumulated in double, scale = 1/sqrtf(mean + eps))
 //   CPY / CONT / DUP        ggml-cpu/ops.cpp ggml_compute_forward_dup (logical element order), f32 <-> f16
 //   SOFT_MAX                ggml-cpu/ops.cpp:4641-4736 (scale, mask f32/f16 broadcast over rows, ALiBi slope, max-subtracted exp)
+//   ROPE                    ggml-cpu/ops.cpp:4990-5270 (normal / neox, YaRN, frequency factors)
+//   MUL_MAT f16/f32 x f32   ggml-cpu.c:1266-1458 with vec_dot_type F16 / F32 (attention KQ, KQV)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -142,6 +144,59 @@ __global__ void __launch_bounds__(256) k_soft_max(const TensorD a, const TensorD
     for (int64_t i = lane; i < nc; i += 64) dp[i] = __fmul_rn(dp[i], inv);
 }
 
+// ---- ROPE (normal and neox modes, YaRN scaling, optional frequency factors): one thread per rotated pair ------------
+//   ggml-cpu/ops.cpp:4990-5028 (rope_yarn, ggml_rope_cache_init), :5088-5270 (ggml_compute_forward_rope_f32)
+struct RopeP { int n_dims, neox; float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1; };
+
+__global__ void __launch_bounds__(256) k_rope(const TensorD a, const int32_t * pos, const float * freq_factors, const TensorD d, const RopeP p, int64_t n_pairs) {
+    const int64_t half = a.ne[0] / 2;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t ip = i % half, r = i / half, i1 = r % a.ne[1], r2 = r / a.ne[1], i2 = r2 % a.ne[2], i3 = r2 / a.ne[2];
+        const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+        char * dst = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+        const int64_t i0 = 2 * ip;
+        if (i0 >= p.n_dims) {                                   // channels beyond n_dims are copied
+            ((float *) dst)[i0] = ((const float *) src)[i0]; ((float *) dst)[i0 + 1] = ((const float *) src)[i0 + 1];
+            continue;
+        }
+        const float ff = freq_factors ? freq_factors[ip] : 1.0f;
+        const float theta_extrap = __fdiv_rn((float) pos[i2] * powf(p.theta_scale, (float) ip), ff);
+        const float theta_interp = p.freq_scale * theta_extrap;
+        float theta = theta_interp, mscale = p.attn_factor;
+        if (p.ext_factor != 0.0f) {
+            const float y = ((float) (i0 / 2) - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
+            const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * p.ext_factor;
+            theta = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+            mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+        }
+        const float c = cosf(theta) * mscale, sn = sinf(theta) * mscale;
+        const int64_t e0 = p.neox ? ip : i0, e1 = p.neox ? ip + p.n_dims / 2 : i0 + 1;
+        const float x0 = ((const float *) src)[e0], x1 = ((const float *) src)[e1];
+        ((float *) dst)[e0] = x0 * c - x1 * sn;
+        ((float *) dst)[e1] = x0 * sn + x1 * c;
+    }
+}
+
+// ---- MUL_MAT with an f16 / f32 src0 (attention KQ and KQV): one wave per output element ---------------------------
+//   dst[m, n, i12, i13] = sum_k a[k, m, i12/r2, i13/r3] * b[k, n, i12, i13]   (ggml-cpu.c:1266-1458; an f16 src0 makes the CPU
+//   round src1 to f16 first, vec_dot_type = F16 -- reproduced; the products are accumulated in f32)
+__global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const TensorD b, const TensorD d, int64_t n_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (o >= n_out) return;
+    const int64_t m = o % d.ne[0], r = o / d.ne[0], n = r % d.ne[1], r2 = r / d.ne[1], i12 = r2 % d.ne[2], i13 = r2 / d.ne[2];
+    const int64_t i02 = i12 / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
+    const char * ap = a.data + m * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3];
+    const float * bp = (const float *) (b.data + n * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3]);
+    const int64_t K = a.ne[0];
+    float s = 0.0f;
+    if (a.type == 1) for (int64_t k = lane; k < K; k += 64) s += __half2float(((const __half *) ap)[k]) * __half2float(__float2half_rn(bp[k]));
+    else             for (int64_t k = lane; k < K; k += 64) s += ((const float *) ap)[k] * bp[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) *(float *) (d.data + m * d.nb[0] + n * d.nb[1] + i12 * d.nb[2] + i13 * d.nb[3]) = s;
+}
+
 static int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 } // namespace mi355q
@@ -220,6 +275,38 @@ int mi355q_op_soft_max(const mi355q_tensor * a, const mi355q_tensor * mask, cons
     TensorD md = mask ? to_d(mask) : to_d(a);
     hipLaunchKernelGGL(k_soft_max, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias,
                        m0, m1, n_head_log2, nrows, mask ? 1 : 0);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_rope(const mi355q_tensor * a, const int32_t * pos, const float * freq_factors, const mi355q_tensor * dst,
+                   const mi355q_rope_params * p, void * stream) {
+    if (!a || !dst || !pos || !p || !same_shape(a, dst) || a->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_rope: f32 tensors of one shape, positions");
+    if (a->nb[0] != 4 || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_rope: rows must be contiguous");
+    if (p->mode != 0 && p->mode != 2) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_rope: only the normal (0) and neox (2) modes");
+    if (p->n_dims <= 0 || p->n_dims % 2 || p->n_dims > a->ne[0] || a->ne[0] % 2) OPS_FAIL(MI355Q_ERR_SHAPE, "op_rope: n_dims must be even and <= ne0");
+    const int64_t n_pairs = nelements(a) / 2;
+    if (n_pairs == 0) return MI355Q_OK;
+    RopeP rp;
+    rp.n_dims = p->n_dims; rp.neox = p->mode == 2; rp.freq_scale = p->freq_scale; rp.ext_factor = p->ext_factor; rp.attn_factor = p->attn_factor;
+    rp.theta_scale = powf(p->freq_base, -2.0f / p->n_dims);
+    // ggml_rope_yarn_corr_dims, ggml.c:3729-3743
+    auto corr_dim = [&](float n_rot) { return p->n_dims * logf(p->n_ctx_orig / (n_rot * 2 * 3.14159265358979323846f)) / (2 * logf(p->freq_base)); };
+    const float start = floorf(corr_dim(p->beta_fast)), end = ceilf(corr_dim(p->beta_slow));
+    rp.corr0 = start > 0 ? start : 0; rp.corr1 = end < p->n_dims - 1 ? end : (float) (p->n_dims - 1);
+    hipLaunchKernelGGL(k_rope, dim3(grid_for(n_pairs)), dim3(256), 0, (hipStream_t) stream, to_d(a), pos, freq_factors, to_d(dst), rp, n_pairs);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const mi355q_tensor * dst, void * stream) {
+    if (!a || !b || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_mul_mat_f: null tensor");
+    if ((a->type != 0 && a->type != 1) || b->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: src0 f16/f32, src1 and dst f32");
+    if (a->ne[0] != b->ne[0] || dst->ne[0] != a->ne[1] || dst->ne[1] != b->ne[1] || dst->ne[2] != b->ne[2] || dst->ne[3] != b->ne[3] ||
+        a->ne[2] <= 0 || a->ne[3] <= 0 || b->ne[2] % a->ne[2] || b->ne[3] % a->ne[3]) OPS_FAIL(MI355Q_ERR_SHAPE, "op_mul_mat_f: shapes");
+    if (a->nb[0] != (a->type == 0 ? 4 : 2) || b->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: the k dimension must be contiguous in both operands");
+    const int64_t n_out = nelements(dst);
+    if (n_out == 0) return MI355Q_OK;
+    if ((n_out + 3) / 4 > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: too many outputs");
+    hipLaunchKernelGGL(k_mul_mat_f, dim3((unsigned) ((n_out + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n_out);
     OPS_LAUNCHED();
 }
 

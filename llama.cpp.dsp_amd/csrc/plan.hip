@@ -459,8 +459,8 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
         hipMalloc((void **) &pl->d_sync, PLAN_SYNC_WORDS * sizeof(unsigned)) != hipSuccess ||
         hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(pl->d_sync, 0, PLAN_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) {
-        if (pl->d_stages) hipFree(pl->d_stages);
-        if (pl->d_sync) hipFree(pl->d_sync);
+        if (pl->d_stages) (void) hipFree(pl->d_stages);
+        if (pl->d_sync) (void) hipFree(pl->d_sync);
         delete pl; mi355q_set_error("plan_create: device allocation failed"); return MI355Q_ERR_HIP;
     }
     *out = (mi355q_plan *) pl;
@@ -496,7 +496,7 @@ int     mi355q_plan_launch_stages(const mi355q_plan * plan) { return plan ? ((co
 int mi355q_plan_destroy(mi355q_plan * plan) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_OK;
-    hipFree(pl->d_stages); hipFree(pl->d_sync);
+    (void) hipFree(pl->d_stages); (void) hipFree(pl->d_sync);
     delete pl;
     return MI355Q_OK;
 }

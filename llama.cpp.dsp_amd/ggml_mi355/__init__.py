@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
     "mi355q_plan_destroy",
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
+    "mi355q_op_rope", "mi355q_op_mul_mat_f",
 ]
 
 
@@ -71,6 +72,11 @@ class _Stage(C.Structure):
 
 
 STAGE_DEPENDS = 0x1
+
+
+class _RopeParams(C.Structure):
+    _fields_ = [("n_dims", C.c_int), ("mode", C.c_int), ("n_ctx_orig", C.c_int), ("freq_base", C.c_float), ("freq_scale", C.c_float),
+                ("ext_factor", C.c_float), ("attn_factor", C.c_float), ("beta_fast", C.c_float), ("beta_slow", C.c_float)]
 
 
 class _Tensor(C.Structure):
@@ -121,6 +127,8 @@ def lib() -> C.CDLL:
     L.mi355q_op_rms_norm.argtypes = [TP, TP, C.c_float, vp]
     L.mi355q_op_cpy.argtypes = [TP, TP, vp]
     L.mi355q_op_soft_max.argtypes = [TP, TP, TP, C.c_float, C.c_float, vp]
+    L.mi355q_op_rope.argtypes = [TP, vp, vp, TP, C.POINTER(_RopeParams), vp]
+    L.mi355q_op_mul_mat_f.argtypes = [TP, TP, TP, vp]
     L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64]
     L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     _lib = L
@@ -345,6 +353,26 @@ def op_soft_max(a, mask=None, scale: float = 1.0, max_bias: float = 0.0, out=Non
     out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
     _check(lib().mi355q_op_soft_max(C.byref(_td(a)), C.byref(_td(mask)) if mask is not None else None, C.byref(_td(out)), scale, max_bias,
                                     _stream(torch)), "op_soft_max")
+    return out
+
+
+def op_rope(a, pos, n_dims: int, mode: int = 0, freq_factors=None, n_ctx_orig: int = 0, freq_base: float = 10000.0, freq_scale: float = 1.0,
+            ext_factor: float = 0.0, attn_factor: float = 1.0, beta_fast: float = 32.0, beta_slow: float = 1.0, out=None):
+    """GGML_OP_ROPE on a [ne3, ne2 (positions), ne1 (heads), ne0] tensor (torch order); pos: int32 [ne2]."""
+    torch = _torch()
+    out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
+    p = _RopeParams(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
+    _check(lib().mi355q_op_rope(C.byref(_td(a)), pos.data_ptr(), freq_factors.data_ptr() if freq_factors is not None else None,
+                                C.byref(_td(out)), C.byref(p), _stream(torch)), "op_rope")
+    return out
+
+
+def op_mul_mat_f(a, b, out=None):
+    """GGML_OP_MUL_MAT with an f16/f32 src0: a [.., M, K], b [.., N, K] (torch order) -> [.., N, M] f32."""
+    torch = _torch()
+    if out is None:
+        out = torch.empty(tuple(b.shape[:-2]) + (b.shape[-2], a.shape[-2]), dtype=torch.float32, device=b.device)
+    _check(lib().mi355q_op_mul_mat_f(C.byref(_td(a)), C.byref(_td(b)), C.byref(_td(out)), _stream(torch)), "op_mul_mat_f")
     return out
 
 

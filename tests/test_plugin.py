@@ -79,7 +79,7 @@ def test_reference_test_backend_ops(op):
 @pytest.mark.gpu
 @needs_plugin
 @pytest.mark.parametrize("op", ["ADD", "SUB", "MUL", "DIV", "RMS_NORM", "SILU", "RELU", "SIGMOID", "TANH", "NEG", "ABS",
-                                "CPY", "CONT", "DUP", "SOFT_MAX"])
+                                "CPY", "CONT", "DUP", "SOFT_MAX", "ROPE"])
 def test_reference_test_backend_ops_residency(op):
     """The residency ops through the reference's own harness: every case the plugin accepts must pass the
     harness' NMSE check against the ggml CPU backend; cases it declines are reported 'not supported' (never FAIL)."""
