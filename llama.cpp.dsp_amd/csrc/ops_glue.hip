@@ -97,7 +97,10 @@ __global__ void __launch_bounds__(256) k_rms_norm(const TensorD a, const TensorD
     for (int64_t i = lane; i < n; i += 64) s += (double) __fmul_rn(x[i], x[i]);       // (ggml_float)(x*x): the square is rounded to f32 first
     s = wave_sum_f64(s);
     const float mean = (float) (s / (double) n);
-    const float scale = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(mean, eps)));
+    // 1.0f / sqrtf(mean + eps) with BOTH roundings of the CPU: the compiler folds the f32 form into v_rsq_f32 (1 ulp off in ~20 % of
+    // rows) whatever intrinsics spell it, so each step is done in f64 and rounded to f32
+    const float root  = (float) sqrt((double) __fadd_rn(mean, eps));
+    const float scale = (float) (1.0 / (double) root);
     for (int64_t i = lane; i < n; i += 64) y[i] = __fmul_rn(x[i], scale);
 }
 
@@ -160,7 +163,11 @@ __global__ void __launch_bounds__(256) k_rope(const TensorD a, const int32_t * p
             continue;
         }
         const float ff = freq_factors ? freq_factors[ip] : 1.0f;
-        const float theta_extrap = __fdiv_rn((float) pos[i2] * powf(p.theta_scale, (float) ip), ff);
+        // theta is advanced by repeated f32 multiplication exactly as ggml_rope_cache_init does (pos * powf(scale, ip) differs by up
+        // to 1e-6 relative after 64 steps -- 1e-3 rad at position 8191)
+        float th = (float) pos[i2];
+        for (int64_t j = 0; j < ip; ++j) th = __fmul_rn(th, p.theta_scale);
+        const float theta_extrap = __fdiv_rn(th, ff);
         const float theta_interp = p.freq_scale * theta_extrap;
         float theta = theta_interp, mscale = p.attn_factor;
         if (p.ext_factor != 0.0f) {

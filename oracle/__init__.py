@@ -153,6 +153,8 @@ class Reference:
         L.ref_mul_mat_id.argtypes = [_i32, _vp, _vp, _vp, _vp] + [_i64] * 6 + [_i32]
         L.ref_bench_chain.restype = C.c_double
         L.ref_bench_chain.argtypes = [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32]
+        if hasattr(L, "ref_glue_op"):
+            L.ref_glue_op.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]
 
     def blck_size(self, t): return self.lib.ref_blck_size(t)
     def type_size(self, t): return self.lib.ref_type_size(t)
@@ -209,6 +211,25 @@ class Reference:
         rc = self.lib.ref_mul_mat_id(t, _ptr(as_), _ptr(b), _ptr(ids), _ptr(dst), M, K, n_expert, n_used, n_tok, b.shape[1], n_threads)
         assert rc == 0, rc
         return dst
+
+    def glue_op(self, op: int, a, b=None, pos=None, fparams=(), iparams=(), out_shape=None):
+        """One residency op on the reference CPU backend (refshim ref_glue_op); arrays are numpy with ggml dims REVERSED
+        (numpy shape [ne3, ne2, ne1, ne0], leading dims optional)."""
+        def ne(x):
+            sh = list(x.shape)[::-1] + [1] * (4 - x.ndim)
+            return np.asarray(sh, np.int64)
+        a = np.ascontiguousarray(a, np.float32)
+        nea = ne(a)
+        bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+        neb = ne(bb) if bb is not None else np.zeros(4, np.int64)
+        pp = np.ascontiguousarray(pos, np.int32) if pos is not None else None
+        fp = np.asarray(list(fparams) + [0.0] * 8, np.float32); ip = np.asarray(list(iparams) + [0] * 8, np.int32)
+        out = np.empty(out_shape if out_shape is not None else a.shape, np.float32)
+        rc = self.lib.ref_glue_op(op, _ptr(a), _ptr(nea), _ptr(bb) if bb is not None else None, _ptr(neb), _ptr(pp) if pp is not None else None,
+                                  _ptr(fp), _ptr(ip), _ptr(out), 1)
+        if rc != 0:
+            raise RuntimeError(f"ref_glue_op({op}) failed: {rc}")
+        return out
 
     def bench_chain(self, types, Ms, Ks, N: int, n_threads: int, warmup: int, iters: int) -> float:
         ty = np.asarray(types, np.int32); ms = np.asarray(Ms, np.int64); ks = np.asarray(Ks, np.int64)

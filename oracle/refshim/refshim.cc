@@ -175,4 +175,46 @@ double ref_bench_chain(int n_mats, const int * types, const int64_t * Ms, const 
     return std::chrono::duration<double>(t1 - t0).count() / (iters > 0 ? iters : 1);
 }
 
+
+// ---- residency ops on the reference CPU backend: one op on contiguous f32 tensors -----------------
+// op: 1 ADD, 2 SUB, 3 MUL, 4 DIV (b broadcast over a), 10 RMS_NORM (fp[0] = eps), 11 SILU, 12 SOFT_MAX (b = f32 mask or NULL,
+// fp[0] = scale, fp[1] = max_bias), 13 ROPE (ip = {n_dims, mode, n_ctx_orig}, fp = {freq_base, freq_scale, ext_factor,
+// attn_factor, beta_fast, beta_slow}, pos = i32 [ne_a[2]], b = freq factors [n_dims/2] or NULL), 14 MUL_MAT with an f16 src0
+// (a is given as f32 and rounded to f16 here), 15 MUL_MAT f32.  ne_*: ggml order.  Returns 0 on success.
+int ref_glue_op(int op, const float * a, const int64_t * ne_a, const float * b, const int64_t * ne_b, const int32_t * pos,
+                const float * fp, const int32_t * ip, float * out, int n_threads) {
+    const int64_t na = ne_a[0] * ne_a[1] * ne_a[2] * ne_a[3];
+    const int64_t nbn = b ? ne_b[0] * ne_b[1] * ne_b[2] * ne_b[3] : 0;
+    struct ggml_init_params ipar = { (size_t) (na + nbn) * 16 + (size_t) 256 * 1024 * 1024, nullptr, false };
+    struct ggml_context * ctx = ggml_init(ipar);
+    if (!ctx) return 1;
+    struct ggml_tensor * ta = ggml_new_tensor_4d(ctx, op == 14 ? GGML_TYPE_F16 : GGML_TYPE_F32, ne_a[0], ne_a[1], ne_a[2], ne_a[3]);
+    if (op == 14) ggml_fp32_to_fp16_row(a, (ggml_fp16_t *) ta->data, na); else memcpy(ta->data, a, (size_t) na * 4);
+    struct ggml_tensor * tb = nullptr;
+    if (b) { tb = ggml_new_tensor_4d(ctx, GGML_TYPE_F32, ne_b[0], ne_b[1], ne_b[2], ne_b[3]); memcpy(tb->data, b, (size_t) nbn * 4); }
+    struct ggml_tensor * c = nullptr;
+    switch (op) {
+    case 1: c = ggml_add(ctx, ta, tb); break;
+    case 2: c = ggml_sub(ctx, ta, tb); break;
+    case 3: c = ggml_mul(ctx, ta, tb); break;
+    case 4: c = ggml_div(ctx, ta, tb); break;
+    case 10: c = ggml_rms_norm(ctx, ta, fp[0]); break;
+    case 11: c = ggml_silu(ctx, ta); break;
+    case 12: c = ggml_soft_max_ext(ctx, ta, tb, fp[0], fp[1]); break;
+    case 13: {
+        struct ggml_tensor * tp = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, ne_a[2]);
+        memcpy(tp->data, pos, (size_t) ne_a[2] * 4);
+        c = ggml_rope_ext(ctx, ta, tp, tb, ip[0], ip[1], ip[2], fp[0], fp[1], fp[2], fp[3], fp[4], fp[5]);
+    } break;
+    case 14: case 15: c = ggml_mul_mat(ctx, ta, tb); break;
+    default: ggml_free(ctx); return 3;
+    }
+    struct ggml_cgraph * gf = ggml_new_graph(ctx);
+    ggml_build_forward_expand(gf, c);
+    enum ggml_status st = ggml_graph_compute_with_ctx(ctx, gf, n_threads);
+    if (st == GGML_STATUS_SUCCESS) memcpy(out, c->data, ggml_nbytes(c));
+    ggml_free(ctx);
+    return st == GGML_STATUS_SUCCESS ? 0 : 2;
+}
+
 } // extern "C"

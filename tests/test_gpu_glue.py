@@ -1,0 +1,126 @@
+"""Residency ops through the C-ABI (mi355q_op_*) against the numpy oracle (oracle/glue.py, itself pinned
+against the real reference in tests/test_oracle_glue.py), at Llama-3-8B decode / small-prefill shapes, including the strided
+and broadcast operands the decode graph produces (permuted q, KV-cache views)."""
+import numpy as np
+import pytest
+
+from oracle import glue
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    import ggml_mi355 as g
+    assert torch.cuda.is_available() and g.lib().mi355q_device_count() >= 1
+    return g
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    return t
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_bin_bcast_bitexact(G, torch):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((2, 3, 5, 4096)).astype(np.float32)
+    for shape in ((2, 3, 5, 4096), (1, 1, 1, 4096), (1, 3, 1, 4096), (1, 1, 5, 1)):
+        b = rng.uniform(0.5, 2.0, shape).astype(np.float32)
+        for code, name in ((G.OP_ADD, "add"), (G.OP_SUB, "sub"), (G.OP_MUL, "mul"), (G.OP_DIV, "div")):
+            y = G.op_bin_bcast(code, dev(torch, a), dev(torch, b)).cpu().numpy()
+            assert np.array_equal(bits(y), bits(glue.bin_bcast(name, a, b))), (name, shape)
+    # a strided (permuted) src0 and an in-place destination, as the residual adds of the graph do
+    at = dev(torch, a).permute(0, 2, 1, 3)
+    y = G.op_bin_bcast(G.OP_ADD, at, dev(torch, a.transpose(0, 2, 1, 3).copy())).cpu().numpy()
+    assert np.array_equal(bits(y), bits(2 * a.transpose(0, 2, 1, 3)))
+
+
+def test_rms_norm(G, torch):
+    rng = np.random.default_rng(2)
+    for shape, eps in (((1, 1, 1, 4096), 1e-5), ((1, 1, 7, 4096), 1e-5), ((2, 3, 5, 64), 1e-6), ((1, 1, 2, 14336), 1e-5), ((1, 1, 3, 100), 0.0)):
+        x = (rng.standard_normal(shape) * rng.uniform(0.01, 30.0)).astype(np.float32)
+        y = G.op_rms_norm(dev(torch, x), eps).cpu().numpy()
+        ref = glue.rms_norm(x, eps)
+        assert np.abs(y - ref).max() <= 1.5e-7 * np.abs(ref).max(), shape          # (only the order of the f64 sum differs)
+        assert (bits(y) == bits(ref)).mean() > 0.999
+
+
+def test_unary_and_cpy(G, torch):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((1, 1, 4, 14336)) * 4).astype(np.float32)
+    y = G.op_unary(G.UNARY_SILU, dev(torch, x)).cpu().numpy()
+    ref = glue.silu(x)
+    assert np.abs(y - ref).max() <= 5e-7 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(G.op_unary(G.UNARY_RELU, dev(torch, x)).cpu().numpy(), np.maximum(x, 0))
+    # CPY f32 -> f16 into a strided KV-cache view (row pitch larger than the row), and back
+    k = rng.standard_normal((1, 1, 8, 128)).astype(np.float32)
+    cache = torch.zeros((1, 1, 8, 256), dtype=torch.float16, device="cuda")
+    G.op_cpy(dev(torch, k), cache[..., 64:192])
+    assert np.array_equal(cache[..., 64:192].cpu().numpy(), k.astype(np.float16))
+    assert float(cache[..., :64].abs().max()) == 0.0 and float(cache[..., 192:].abs().max()) == 0.0
+    back = torch.empty((1, 1, 8, 128), dtype=torch.float32, device="cuda")
+    G.op_cpy(cache[..., 64:192], back)
+    assert np.array_equal(back.cpu().numpy(), k.astype(np.float16).astype(np.float32))
+    # CONT of a permuted tensor (logical element order)
+    p = dev(torch, k).permute(0, 1, 3, 2)
+    out = torch.empty((1, 1, 128, 8), dtype=torch.float32, device="cuda")
+    G.op_cpy(p, out)
+    assert np.array_equal(out.cpu().numpy(), k.transpose(0, 1, 3, 2))
+
+
+def test_soft_max(G, torch):
+    rng = np.random.default_rng(4)
+    kq = (rng.standard_normal((1, 32, 3, 513)) * 3).astype(np.float32)
+    mask = np.where(rng.random((3, 513)) < 0.2, -np.inf, 0.0).astype(np.float32); mask[:, 0] = 0
+    for m, mb in ((mask, 0.0), (mask, 8.0), (None, 0.0)):
+        y = G.op_soft_max(dev(torch, kq), dev(torch, m) if m is not None else None, 0.0884, mb).cpu().numpy()
+        ref = glue.soft_max(kq, m, 0.0884, mb)
+        assert np.abs(y - ref).max() <= 3e-7 and np.allclose(y.sum(-1), 1.0, atol=1e-5)
+    y16 = G.op_soft_max(dev(torch, kq), dev(torch, mask).half(), 0.0884, 0.0).cpu().numpy()       # f16 mask (the graph's KQ mask)
+    assert np.abs(y16 - glue.soft_max(kq, mask, 0.0884, 0.0)).max() <= 3e-7
+
+
+def test_rope(G, torch):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 5, 32, 128)).astype(np.float32)
+    pos = np.array([0, 1, 17, 1000, 8191], np.int32)
+    ff = rng.uniform(1.0, 8.0, 64).astype(np.float32)
+    for mode in (0, 2):
+        for n_dims, freq, fscale, ext in ((128, None, 1.0, 0.0), (64, None, 1.0, 0.0), (128, ff, 1.0, 0.0), (128, None, 0.25, 1.0)):
+            y = G.op_rope(dev(torch, x), dev(torch, pos), n_dims, mode, dev(torch, freq[:n_dims // 2]) if freq is not None else None,
+                          8192, 500000.0, fscale, ext, 1.0, 32.0, 1.0).cpu().numpy()
+            ref = glue.rope(x, pos, n_dims, mode, freq, 8192, 500000.0, fscale, ext, 1.0, 32.0, 1.0)
+            assert np.abs(y - ref).max() <= 6e-5 * np.abs(ref).max(), (mode, n_dims, fscale, ext)
+    with pytest.raises(G.Mi355qError):
+        G.op_rope(dev(torch, x), dev(torch, pos), 128, 8)                                            # mrope: not on the device
+
+
+def test_mul_mat_f_attention_shapes(G, torch):
+    rng = np.random.default_rng(6)
+    n_kv, hd, nh, nkvh, nt = 300, 128, 32, 8, 2
+    # KQ: K cache view [n_head_kv, n_kv, head_dim] with a row pitch of n_embd_k_gqa f16; q permuted to [n_head, n_tokens, head_dim]
+    kc = rng.standard_normal((n_kv, nkvh * hd)).astype(np.float32)
+    k_view = dev(torch, kc).half().view(n_kv, nkvh, hd).permute(1, 0, 2)[None]
+    q = rng.standard_normal((nt, nh, hd)).astype(np.float32)
+    q_view = dev(torch, q).permute(1, 0, 2)[None]
+    y = G.op_mul_mat_f(k_view, q_view).cpu().numpy()
+    ref = glue.mul_mat_f(kc.reshape(n_kv, nkvh, hd).transpose(1, 0, 2)[None], q.transpose(1, 0, 2)[None], True)
+    assert y.shape == (1, nh, nt, n_kv) and np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+    # KQV: transposed V cache [n_head_kv, head_dim, n_kv] f16 times the soft-max output [n_head, n_tokens, n_kv]
+    v = rng.standard_normal((1, nkvh, hd, n_kv)).astype(np.float32)
+    p = rng.random((1, nh, nt, n_kv)).astype(np.float32)
+    y = G.op_mul_mat_f(dev(torch, v).half(), dev(torch, p)).cpu().numpy()
+    assert np.abs(y - glue.mul_mat_f(v, p, True)).max() <= 2e-5 * np.abs(y).max()
+    # f32 src0
+    y = G.op_mul_mat_f(dev(torch, v), dev(torch, p)).cpu().numpy()
+    assert np.abs(y - glue.mul_mat_f(v, p, False)).max() <= 2e-5 * np.abs(y).max()

@@ -1,0 +1,76 @@
+"""The numpy restatement of the residency ops (oracle/glue.py) against the REAL reference CPU backend (oracle/_ref through
+refshim ref_glue_op) at Llama decode shapes.  Elementwise / norm ops must agree bit for bit with the scalar reference build;
+ops with expf / sinf / cosf or a long f32 dot product within a few ulp."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import glue
+
+pytestmark = pytest.mark.skipif(not oracle.ref_available("scalar"), reason="oracle/_ref/scalar not built")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    r = oracle.Reference("scalar")
+    if not hasattr(r.lib, "ref_glue_op"):
+        pytest.skip("refshim without ref_glue_op (stale oracle/_ref)")
+    return r
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_bin_bcast_bitexact(ref):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((2, 3, 5, 64)).astype(np.float32)
+    for shape in ((2, 3, 5, 64), (1, 1, 1, 64), (1, 3, 1, 64), (1, 1, 5, 1)):
+        b = rng.uniform(0.5, 2.0, shape).astype(np.float32)
+        for code, name in ((1, "add"), (2, "sub"), (3, "mul"), (4, "div")):
+            assert np.array_equal(bits(glue.bin_bcast(name, a, b)), bits(ref.glue_op(code, a, b))), (name, shape)
+
+
+def test_rms_norm_bitexact(ref):
+    rng = np.random.default_rng(2)
+    for shape, eps in (((1, 1, 7, 4096), 1e-5), ((2, 3, 5, 64), 1e-6), ((1, 1, 1, 14336), 1e-5), ((1, 1, 3, 100), 0.0)):
+        x = (rng.standard_normal(shape) * rng.uniform(0.01, 30.0)).astype(np.float32)
+        assert np.array_equal(bits(glue.rms_norm(x, eps)), bits(ref.glue_op(10, x, fparams=[eps]))), shape
+
+
+def test_silu_soft_max_close(ref):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((1, 1, 4, 14336)) * 4).astype(np.float32)
+    r = ref.glue_op(11, x)
+    assert np.abs(glue.silu(x) - r).max() <= 4e-7 * max(1.0, np.abs(r).max())
+    kq = rng.standard_normal((1, 32, 3, 257)).astype(np.float32) * 3
+    mask = np.where(rng.random((3, 257)) < 0.2, -np.inf, 0.0).astype(np.float32); mask[:, 0] = 0
+    for mb in (0.0, 8.0):
+        r = ref.glue_op(12, kq, mask, fparams=[0.0884, mb])
+        o = glue.soft_max(kq, mask, 0.0884, mb)
+        assert np.abs(o - r).max() <= 2e-7 and np.allclose(o.sum(-1), 1.0, atol=1e-5)
+    r = ref.glue_op(12, kq, None, fparams=[1.0, 0.0])
+    assert np.abs(glue.soft_max(kq, None, 1.0) - r).max() <= 2e-7
+
+
+def test_rope_close(ref):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((1, 5, 8, 128)).astype(np.float32)
+    pos = np.array([0, 1, 17, 1000, 8191], np.int32)
+    ff = rng.uniform(1.0, 8.0, 64).astype(np.float32)
+    for mode in (0, 2):
+        for n_dims, freq, fscale, ext in ((128, None, 1.0, 0.0), (64, None, 1.0, 0.0), (128, ff, 1.0, 0.0), (128, None, 0.25, 1.0)):
+            r = ref.glue_op(13, x, freq[:n_dims // 2] if freq is not None else None, pos=pos,
+                            fparams=[500000.0, fscale, ext, 1.0, 32.0, 1.0], iparams=[n_dims, mode, 8192])
+            o = glue.rope(x, pos, n_dims, mode, freq, 8192, 500000.0, fscale, ext, 1.0, 32.0, 1.0)
+            assert np.abs(o - r).max() <= 3e-5 * np.abs(r).max(), (mode, n_dims, fscale, ext)      # sinf/cosf of angles up to ~8e3 rad
+
+
+def test_mul_mat_f_close(ref):
+    rng = np.random.default_rng(5)
+    k = rng.standard_normal((1, 8, 300, 128)).astype(np.float32)          # K cache view: [n_head_kv, n_kv, head_dim]
+    q = rng.standard_normal((1, 32, 2, 128)).astype(np.float32)           # [n_head, n_tokens, head_dim]
+    for code, f16 in ((14, True), (15, False)):
+        r = ref.glue_op(code, k, q, out_shape=(1, 32, 2, 300))
+        o = glue.mul_mat_f(k, q, f16)
+        assert np.abs(o - r).max() <= 2e-5 * np.abs(r).max(), code
