@@ -242,6 +242,10 @@ typedef struct mi355q_rope_params {      /* the op_params of GGML_OP_ROPE (ggml.
 int mi355q_op_rope(const mi355q_tensor *a, const int32_t *pos, const float *freq_factors, const mi355q_tensor *dst,
                    const mi355q_rope_params *p, void *stream);
 int mi355q_op_mul_mat_f(const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);
+/* GGML_OP_GET_ROWS: dst[:, i10, i11, i12] = a[:, ids[i10, i11, i12], i11, i12]; a f32/f16, ids i32 (tensor with type field ignored), dst f32.
+ * GGML_OP_SCALE:    dst = a * scale (f32). */
+int mi355q_op_get_rows(const mi355q_tensor *a, const mi355q_tensor *ids, const mi355q_tensor *dst, void *stream);
+int mi355q_op_scale(const mi355q_tensor *a, const mi355q_tensor *dst, float scale, void *stream);
 
 #ifdef __cplusplus
 }

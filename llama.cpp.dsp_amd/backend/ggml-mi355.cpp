@@ -309,6 +309,14 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
         if (dst->src[1]) { const mi355q_tensor m = mi355_td(dst->src[1]); MQ_CHECK(mi355q_op_soft_max(&a, &m, &d, scale, max_bias, ctx->stream)); }
         else MQ_CHECK(mi355q_op_soft_max(&a, nullptr, &d, scale, max_bias, ctx->stream));
     } break;
+    case GGML_OP_GET_ROWS: {
+        mi355q_tensor ids = mi355_td(dst->src[1]);
+        MQ_CHECK(mi355q_op_get_rows(&a, &ids, &d, ctx->stream));
+    } break;
+    case GGML_OP_SCALE: {
+        float sc; memcpy(&sc, dst->op_params, sizeof(float));
+        MQ_CHECK(mi355q_op_scale(&a, &d, sc, ctx->stream));
+    } break;
     case GGML_OP_ROPE: {
         mi355q_rope_params p;
         const int32_t * q = (const int32_t *) dst->op_params;
@@ -339,7 +347,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
             break;
         case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
         case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_UNARY: case GGML_OP_RMS_NORM:
-        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE:
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
             mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
@@ -468,6 +476,15 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
     case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
         const struct ggml_tensor * a = op->src[0];
         return mi355_f32_or_f16(a->type) && mi355_f32_or_f16(op->type) && mi355_operand_ok(a) && ggml_nelements(a) == ggml_nelements(op);
+    }
+    case GGML_OP_GET_ROWS: {
+        const struct ggml_tensor * a = op->src[0];
+        const struct ggml_tensor * ids = op->src[1];
+        return mi355_f32_or_f16(a->type) && op->type == GGML_TYPE_F32 && ids->type == GGML_TYPE_I32 && mi355_operand_ok(a) && mi355_operand_ok(ids);
+    }
+    case GGML_OP_SCALE: {
+        const struct ggml_tensor * a = op->src[0];
+        return a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && mi355_operand_ok(a);
     }
     case GGML_OP_ROPE: {
         const struct ggml_tensor * a = op->src[0];

@@ -10,6 +10,7 @@
 //   CPY / CONT / DUP        ggml-cpu/ops.cpp ggml_compute_forward_dup (logical element order), f32 <-> f16
 //   SOFT_MAX                ggml-cpu/ops.cpp:4641-4736 (scale, mask f32/f16 broadcast over rows, ALiBi slope, max-subtracted exp)
 //   ROPE                    ggml-cpu/ops.cpp:4990-5270 (normal / neox, YaRN, frequency factors)
+//   GET_ROWS, SCALE         ggml-cpu/ops.cpp:4272-4311, 3840-3878
 //   MUL_MAT f16/f32 x f32   ggml-cpu.c:1266-1458 with vec_dot_type F16 / F32 (attention KQ, KQV)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -204,6 +205,28 @@ __global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const Tensor
     if (lane == 0) *(float *) (d.data + m * d.nb[0] + n * d.nb[1] + i12 * d.nb[2] + i13 * d.nb[3]) = s;
 }
 
+// ---- GET_ROWS (f32 / f16 rows -> f32): dst[:, i10, i11, i12] = src0[:, ids[i10, i11, i12], i11, i12]   ops.cpp:4272-4311 -------
+__global__ void __launch_bounds__(256) k_get_rows(const TensorD a, const char * ids, int64_t nb10, int64_t nb11, int64_t nb12,
+                                                  int64_t ne10, int64_t ne11, const TensorD d, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0];
+        const int64_t i12 = r / (ne11 * ne10), i11 = (r - i12 * ne11 * ne10) / ne10, i10 = r - i12 * ne11 * ne10 - i11 * ne10;
+        const int64_t i01 = *(const int32_t *) (ids + i10 * nb10 + i11 * nb11 + i12 * nb12);
+        if (i01 < 0 || i01 >= a.ne[1]) continue;                 // (the reference asserts; the row is left untouched here)
+        const float v = ld_elem(a.data + i0 * a.nb[0] + i01 * a.nb[1] + i11 * a.nb[2] + i12 * a.nb[3], a.type);
+        *(float *) (d.data + i0 * d.nb[0] + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]) = v;
+    }
+}
+
+// ---- SCALE: dst = a * s   (ops.cpp:3840-3878, ggml_vec_scale_f32) -----------------------------------------------------
+__global__ void __launch_bounds__(256) k_scale(const TensorD a, const TensorD d, float sc, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0], i1 = r % d.ne[1], r2 = r / d.ne[1], i2 = r2 % d.ne[2], i3 = r2 / d.ne[2];
+        const float x = *(const float *) (a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+        *(float *) (d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = __fmul_rn(x, sc);
+    }
+}
+
 static int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 } // namespace mi355q
@@ -282,6 +305,26 @@ int mi355q_op_soft_max(const mi355q_tensor * a, const mi355q_tensor * mask, cons
     TensorD md = mask ? to_d(mask) : to_d(a);
     hipLaunchKernelGGL(k_soft_max, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias,
                        m0, m1, n_head_log2, nrows, mask ? 1 : 0);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_get_rows(const mi355q_tensor * a, const mi355q_tensor * ids, const mi355q_tensor * dst, void * stream) {
+    if (!a || !ids || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_get_rows: null tensor");
+    if ((a->type != 0 && a->type != 1) || dst->type != 0) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_get_rows: f32 / f16 rows to f32");
+    if (dst->ne[0] != a->ne[0] || dst->ne[1] != ids->ne[0] || dst->ne[2] != ids->ne[1] || dst->ne[3] != ids->ne[2] || a->ne[2] != ids->ne[1])
+        OPS_FAIL(MI355Q_ERR_SHAPE, "op_get_rows: shapes (dst [ne00, ne10, ne11, ne12], ne02 == ne11)");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_get_rows, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), (const char *) ids->data, ids->nb[0], ids->nb[1], ids->nb[2],
+                       ids->ne[0], ids->ne[1], to_d(dst), n);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_scale(const mi355q_tensor * a, const mi355q_tensor * dst, float scale, void * stream) {
+    if (!a || !dst || !same_shape(a, dst) || a->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_scale: f32 tensors of one shape");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), scale, n);
     OPS_LAUNCHED();
 }
 

@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
     "mi355q_plan_destroy",
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
-    "mi355q_op_rope", "mi355q_op_mul_mat_f",
+    "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale",
 ]
 
 
@@ -129,6 +129,8 @@ def lib() -> C.CDLL:
     L.mi355q_op_soft_max.argtypes = [TP, TP, TP, C.c_float, C.c_float, vp]
     L.mi355q_op_rope.argtypes = [TP, vp, vp, TP, C.POINTER(_RopeParams), vp]
     L.mi355q_op_mul_mat_f.argtypes = [TP, TP, TP, vp]
+    L.mi355q_op_get_rows.argtypes = [TP, TP, TP, vp]
+    L.mi355q_op_scale.argtypes = [TP, TP, C.c_float, vp]
     L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64]
     L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     _lib = L
@@ -364,6 +366,27 @@ def op_rope(a, pos, n_dims: int, mode: int = 0, freq_factors=None, n_ctx_orig: i
     p = _RopeParams(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
     _check(lib().mi355q_op_rope(C.byref(_td(a)), pos.data_ptr(), freq_factors.data_ptr() if freq_factors is not None else None,
                                 C.byref(_td(out)), C.byref(p), _stream(torch)), "op_rope")
+    return out
+
+
+def op_get_rows(a, ids, out=None):
+    """GGML_OP_GET_ROWS: a [.., n_rows, ne0] (f32/f16), ids int32 [.., n_ids] -> f32 [.., n_ids, ne0]."""
+    torch = _torch()
+    assert ids.dtype == torch.int32
+    if out is None:
+        out = torch.empty(tuple(ids.shape) + (a.shape[-1],), dtype=torch.float32, device=a.device)
+    t = _Tensor(); t.data = ids.data_ptr(); t.type = 0
+    shape = list(ids.shape)[::-1] + [1] * (4 - ids.dim()); st = [s_ * 4 for s_ in list(ids.stride())[::-1]]
+    for i in range(4):
+        t.ne[i] = shape[i]; t.nb[i] = st[i] if i < ids.dim() else (t.nb[i - 1] * t.ne[i - 1])
+    _check(lib().mi355q_op_get_rows(C.byref(_td(a)), C.byref(t), C.byref(_td(out)), _stream(torch)), "op_get_rows")
+    return out
+
+
+def op_scale(a, scale: float, out=None):
+    torch = _torch()
+    out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
+    _check(lib().mi355q_op_scale(C.byref(_td(a)), C.byref(_td(out)), scale, _stream(torch)), "op_scale")
     return out
 
 

@@ -79,7 +79,7 @@ def test_reference_test_backend_ops(op):
 @pytest.mark.gpu
 @needs_plugin
 @pytest.mark.parametrize("op", ["ADD", "SUB", "MUL", "DIV", "RMS_NORM", "SILU", "RELU", "SIGMOID", "TANH", "NEG", "ABS",
-                                "CPY", "CONT", "DUP", "SOFT_MAX", "ROPE"])
+                                "CPY", "CONT", "DUP", "SOFT_MAX", "ROPE", "GET_ROWS", "SCALE"])
 def test_reference_test_backend_ops_residency(op):
     """The residency ops through the reference's own harness: every case the plugin accepts must pass the
     harness' NMSE check against the ggml CPU backend; cases it declines are reported 'not supported' (never FAIL)."""
@@ -93,3 +93,20 @@ def test_reference_test_backend_ops_residency(op):
     ran = [l for l in cases if "OK" in l]
     print(f"{op}: {len(ran)} of {len(cases)} cases ran on MI355_0 and passed")
     assert len(ran) >= 1, tail
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("n_tokens", [1, 3])
+def test_decode_layer_resident_and_equal_to_cpu(n_tokens):
+    """One llama decoder layer (norms, quantized projections, rope, KV-cache stores, f16 attention matmuls, softmax, residuals,
+    SiLU FFN) built with the reference's graph API: the plugin must accept EVERY node (the layer stays resident on the device)
+    and reproduce the CPU backend's layer output and KV-cache contents (oracle/layer_parity/layer_parity.cc)."""
+    exe = _harness().parent / "layer_parity"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/*/layer_parity not built")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN))
+    r = subprocess.run([str(exe), str(n_tokens), "MI355_0"], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 refused by MI355_0" in r.stdout and "LAYER PARITY OK" in r.stdout
