@@ -7,8 +7,11 @@
 // contents, and compares the layer output and the updated KV cache.  It also asks the device backend supports_op() for every
 // node: a decode layer is "resident" only if none is refused (each refusal is a scheduler split with a PCIe round trip).
 //
-//   GGML_BACKEND_PATH=.../libggml-mi355.so layer_parity [n_tokens] [device name]
+//   GGML_BACKEND_PATH=.../libggml-mi355.so layer_parity [n_tokens] [device name] [8b [iters]]
 // exit code 0 = all nodes supported and NMSE(out), NMSE(k cache), NMSE(v cache) below 5e-4 / 1e-6.
+// With "8b": Llama-3-8B dimensions (n_embd 4096, n_ff 14336, 32/8 heads, 512 cached positions) and a timing loop of
+// graph_compute on both backends (one layer of a decode step through the reference's own graph API).
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -105,6 +108,9 @@ int main(int argc, char ** argv) {
     ggml_backend_t be_dev = ggml_backend_dev_init(dev, nullptr);
     ggml_backend_t be_cpu = ggml_backend_init_by_type(GGML_BACKEND_DEVICE_TYPE_CPU, nullptr);
     Dims d;
+    const bool big = argc > 3 && std::string(argv[3]) == "8b";
+    const int iters = argc > 4 ? atoi(argv[4]) : 50;
+    if (big) { d.n_embd = 4096; d.n_head = 32; d.n_head_kv = 8; d.hd = 128; d.n_ff = 14336; d.n_ctx = 1024; d.n_past = 511; }
     Layer ref = build(d, n_tokens, be_cpu), tst = build(d, n_tokens, be_dev);
 
     // ---- the same data for both
@@ -153,6 +159,17 @@ int main(int argc, char ** argv) {
     const double e_out = nmse(get_f32(tst.out), get_f32(ref.out));
     const double e_k = nmse(get_f16(tst.kc), get_f16(ref.kc)), e_v = nmse(get_f16(tst.vc), get_f16(ref.vc));
     printf("n_tokens=%d n_kv=%d  NMSE out %.3e  k cache %.3e  v cache %.3e\n", n_tokens, n_kv, e_out, e_k, e_v);
+    if (big) {
+        auto time_it = [&](ggml_backend_t be, ggml_cgraph * gf, int n) {
+            ggml_backend_graph_compute(be, gf);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < n; ++i) ggml_backend_graph_compute(be, gf);
+            return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+        };
+        const double us_dev = time_it(be_dev, tst.gf, iters), us_cpu = time_it(be_cpu, ref.gf, iters < 10 ? iters : 10);
+        printf("one Llama-3-8B decoder layer (n_tokens=%d, n_kv=%d, %d graph nodes) through ggml_backend_graph_compute: %s %.1f us, CPU backend %.1f us\n",
+               n_tokens, n_kv, ggml_graph_n_nodes(tst.gf), dev_name.c_str(), us_dev, us_cpu);
+    }
     const bool ok = e_out <= 5e-4 && e_k <= 1e-6 && e_v <= 1e-6 && std::isfinite(e_out);
     printf("%s\n", ok ? "LAYER PARITY OK" : "LAYER PARITY FAILED");
     return ok ? 0 : 1;
