@@ -244,8 +244,20 @@ int mi355q_op_rope(const mi355q_tensor *a, const int32_t *pos, const float *freq
 int mi355q_op_mul_mat_f(const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);
 /* GGML_OP_GET_ROWS: dst[:, i10, i11, i12] = a[:, ids[i10, i11, i12], i11, i12]; a f32/f16, ids i32 (tensor with type field ignored), dst f32.
  * GGML_OP_SCALE:    dst = a * scale (f32). */
+/* op_cpy whose destination base pointer is read ON THE DEVICE from dest_table[index] (dst->data is ignored): lets a captured
+ * launch graph be replayed while the KV-cache store position moves every token (cf. ggml-cuda.cu cpy_dest_ptrs). */
+int mi355q_op_cpy_indirect(const mi355q_tensor *a, const mi355q_tensor *dst, void *const *dest_table, int index, void *stream);
 int mi355q_op_get_rows(const mi355q_tensor *a, const mi355q_tensor *ids, const mi355q_tensor *dst, void *stream);
 int mi355q_op_scale(const mi355q_tensor *a, const mi355q_tensor *dst, float scale, void *stream);
+
+/* ---- launch graphs: capture everything enqueued on `stream` between begin and end, replay it with one call ---------------
+ * (hipStreamBeginCapture / hipStreamEndCapture / hipGraphInstantiate / hipGraphLaunch; the reference's counterpart is the CUDA
+ * graph path of ggml-cuda.cu:2470-2781).  No allocation or synchronization may happen between begin and end.             */
+typedef struct mi355q_graph mi355q_graph;
+int mi355q_graph_capture_begin(void *stream);
+int mi355q_graph_capture_end(void *stream, mi355q_graph **out);     /* on failure the stream leaves capture mode, *out = NULL */
+int mi355q_graph_launch(mi355q_graph *graph, void *stream);
+int mi355q_graph_destroy(mi355q_graph *graph);
 
 #ifdef __cplusplus
 }

@@ -57,7 +57,18 @@ struct mi355_backend_ctx {
     void *      stream    = nullptr;
     void *      workspace = nullptr;
     size_t      workspace_size = 0;
+    // launch-graph cache of the last compute graph (the reference's counterpart: ggml-cuda.cu:2470-2781)
+    mi355q_graph * graph = nullptr;
+    uint64_t    graph_key = 0;          // hash of the node list the cached / last seen graph was built from
+    int         key_repeats = 0;        // how many consecutive times that key has been seen
+    int         key_changes = 0;        // consecutive key changes: after a few the cache is given up for this backend
+    bool        graphs_disabled = false;
+    void **     dest_table = nullptr;   // device array: destination base pointers of the CPY nodes (updated every compute)
+    std::vector<void *> dest_host;
+    bool        capturing = false;
+    long        n_eager = 0, n_captured = 0, n_replayed = 0;   // graph_compute calls by how they ran (MI355_GRAPH_STATS=1 prints them)
 };
+constexpr int MI355_MAX_CPY_DESTS = 4096;
 
 static ggml_guid_t mi355_guid() {
     static ggml_guid guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x71, 0x6d, 0x61, 0x74, 0x6d, 0x75, 0x6c, 0x2d, 0x31 };
@@ -200,6 +211,7 @@ static bool mi355_buft_is_ours(ggml_backend_buffer_type_t buft) { return buft &&
 // ------------------------------------------------------------------------------------------------ the ops
 static void * mi355_workspace(mi355_backend_ctx * ctx, size_t bytes) {
     if (bytes <= ctx->workspace_size) return ctx->workspace;
+    GGML_ASSERT(!ctx->capturing && "workspace must be sized before a launch graph is captured");
     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
     if (ctx->workspace) mi355q_free(ctx->workspace);
     const size_t want = bytes + (bytes >> 2) + (1u << 20);
@@ -252,6 +264,9 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355q_set_device(ctx->device);
     if (ctx->stream) { mi355q_stream_synchronize(ctx->stream); mi355q_stream_destroy(ctx->stream); }
     if (ctx->workspace) mi355q_free(ctx->workspace);
+    if (getenv("MI355_GRAPH_STATS")) fprintf(stderr, "MI355 graph_compute calls: %ld eager, %ld captured, %ld replayed\n", ctx->n_eager, ctx->n_captured, ctx->n_replayed);
+    if (ctx->graph) mi355q_graph_destroy(ctx->graph);
+    if (ctx->dest_table) mi355q_free(ctx->dest_table);
     delete ctx;
     delete backend;
 }
@@ -280,7 +295,7 @@ static int mi355_unary_code(enum ggml_unary_op u) {
     }
 }
 
-static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
+static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int cpy_index = -1) {
     const mi355q_tensor d = mi355_td(dst);
     const mi355q_tensor a = mi355_td(dst->src[0]);
     switch (dst->op) {
@@ -297,7 +312,8 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
         MQ_CHECK(mi355q_op_rms_norm(&a, &d, eps, ctx->stream));
     } break;
     case GGML_OP_CPY: {                                       // dst = src[1] viewed; data goes src[0] -> dst (ggml.c ggml_cpy_impl)
-        MQ_CHECK(mi355q_op_cpy(&a, &d, ctx->stream));
+        if (cpy_index >= 0) MQ_CHECK(mi355q_op_cpy_indirect(&a, &d, ctx->dest_table, cpy_index, ctx->stream));
+        else                MQ_CHECK(mi355q_op_cpy(&a, &d, ctx->stream));
     } break;
     case GGML_OP_CONT: case GGML_OP_DUP:
         MQ_CHECK(mi355q_op_cpy(&a, &d, ctx->stream));
@@ -333,9 +349,35 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
     }
 }
 
-static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
-    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
-    mi355q_set_device(ctx->device);
+// everything a captured launch depends on, EXCEPT the destination pointer of CPY nodes (read from dest_table on the device)
+static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph) {
+    uint64_t h = 1469598103934665603ull;
+    // hashed a 64-bit word at a time: a token's graph is ~1000 nodes x ~250 bytes and this runs on every graph_compute
+    auto mix = [&](const void * p, size_t n) {
+        const uint8_t * b = (const uint8_t *) p;
+        for (; n >= 8; n -= 8, b += 8) { uint64_t w; memcpy(&w, b, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+        if (n) { uint64_t w = 0; memcpy(&w, b, n); w |= (uint64_t) n << 56; h =(h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    };
+    auto mix_tensor = [&](const struct ggml_tensor * t, bool with_data) {
+        if (!t) { const int z = 0; mix(&z, sizeof(z)); return; }
+        mix(&t->type, sizeof(t->type)); mix(t->ne, sizeof(t->ne)); mix(t->nb, sizeof(t->nb));
+        if (with_data) mix(&t->data, sizeof(t->data));
+    };
+    for (int i = 0; i < cgraph->n_nodes; ++i) {
+        const struct ggml_tensor * n = cgraph->nodes[i];
+        // views / reshapes launch nothing: what they describe reaches the key through the nodes that consume them (a view into the KV
+        // cache at the store position moves every token and must not invalidate the capture)
+        if (n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE) continue;
+        mix(&n->op, sizeof(n->op)); mix(n->op_params, sizeof(n->op_params));
+        const bool cpy = n->op == GGML_OP_CPY;
+        mix_tensor(n, !cpy);
+        for (int j = 0; j < GGML_MAX_SRC; ++j) mix_tensor(n->src[j], !(cpy && j == 1));
+    }
+    return h;
+}
+
+static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_cgraph * cgraph) {
+    int cpy_index = 0;
     for (int i = 0; i < cgraph->n_nodes; ++i) {
         struct ggml_tensor * node = cgraph->nodes[i];
         if (ggml_is_empty(node)) continue;
@@ -346,14 +388,76 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
             if (mi355_is_quant(node->src[0]->type)) mi355_mul_mat(ctx, node); else mi355_glue_op(ctx, node);
             break;
         case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
+        case GGML_OP_CPY:
+            mi355_glue_op(ctx, node, ctx->dest_table && cpy_index < MI355_MAX_CPY_DESTS ? cpy_index : -1);
+            ++cpy_index;
+            break;
         case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_UNARY: case GGML_OP_RMS_NORM:
-        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
+        case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
             mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
             return GGML_STATUS_FAILED;
         }
     }
+    return GGML_STATUS_SUCCESS;
+}
+
+// The nodes of a decode step are many and tiny (34 per llama layer): issued one by one the step is bound by host launch
+// time.  A graph seen twice in a row is captured into a launch graph and replayed while its key stays the same; the one thing
+// that legitimately moves every token -- where the new K / V rows are stored -- is passed through a device-side pointer table.
+static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    mi355q_set_device(ctx->device);
+    static const bool env_off = getenv("MI355_NO_GRAPHS") != nullptr;
+    const bool try_graphs = !env_off && !ctx->graphs_disabled && cgraph->n_nodes >= 8;
+
+    // destination pointers of the CPY nodes of THIS call
+    int n_cpy = 0;
+    if (try_graphs) {
+        ctx->dest_host.clear();
+        for (int i = 0; i < cgraph->n_nodes; ++i) if (cgraph->nodes[i]->op == GGML_OP_CPY && !ggml_is_empty(cgraph->nodes[i])) ctx->dest_host.push_back(cgraph->nodes[i]->data);
+        n_cpy = (int) ctx->dest_host.size();
+        if (n_cpy > MI355_MAX_CPY_DESTS) n_cpy = -1;
+        else if (n_cpy > 0) {
+            if (!ctx->dest_table) MQ_CHECK(mi355q_malloc((void **) &ctx->dest_table, sizeof(void *) * MI355_MAX_CPY_DESTS));
+            MQ_CHECK(mi355q_memcpy_h2d(ctx->dest_table, ctx->dest_host.data(), sizeof(void *) * n_cpy, ctx->stream));
+        }
+    }
+    enum ggml_status st = GGML_STATUS_SUCCESS;
+    bool done = false;
+    if (try_graphs && n_cpy >= 0) {
+        const uint64_t key = mi355_graph_key(cgraph);
+        if (key == ctx->graph_key) { ++ctx->key_repeats; ctx->key_changes = 0; }
+        else {
+            if (ctx->graph) { mi355q_graph_destroy(ctx->graph); ctx->graph = nullptr; }
+            ctx->graph_key = key; ctx->key_repeats = 0;
+            if (++ctx->key_changes >= 8) ctx->graphs_disabled = true;       // the graph changes every call: capturing would only cost
+        }
+        if (ctx->graph) {                                      // replay
+            MQ_CHECK(mi355q_graph_launch(ctx->graph, ctx->stream));
+            done = true; ++ctx->n_replayed;
+        } else if (ctx->key_repeats >= 1) {                    // second sighting: capture (the first, eager run sized the workspace)
+            if (mi355q_graph_capture_begin(ctx->stream) == MI355Q_OK) {
+                ctx->capturing = true;
+                st = mi355_issue_nodes(ctx, cgraph);
+                ctx->capturing = false;
+                mi355q_graph * g = nullptr;
+                const int rc = mi355q_graph_capture_end(ctx->stream, &g);
+                if (st == GGML_STATUS_SUCCESS && rc == MI355Q_OK && g) {
+                    ctx->graph = g;
+                    MQ_CHECK(mi355q_graph_launch(ctx->graph, ctx->stream));
+                    done = true; ++ctx->n_captured;
+                } else {
+                    if (g) mi355q_graph_destroy(g);
+                    ctx->graphs_disabled = true;               // not capturable on this system: stay eager
+                    st = GGML_STATUS_SUCCESS;
+                }
+            }
+        }
+    }
+    if (!done) { st = mi355_issue_nodes(ctx, cgraph); ++ctx->n_eager; }
+    if (st != GGML_STATUS_SUCCESS) return st;
     // set_tensor/get_tensor of this backend are synchronous copies on the null stream: finish the work before returning
     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
     return GGML_STATUS_SUCCESS;

@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) k_rms_norm(const TensorD a, const TensorD
 }
 
 // ---- CPY / CONT / DUP: logical element order, any strides, f32 <-> f16 -------------------------------------
-__global__ void __launch_bounds__(256) k_cpy(const TensorD a, const TensorD d, int64_t n) {
+__global__ void __launch_bounds__(256) k_cpy(const TensorD a, TensorD d, int64_t n, char * const * dest_table, int dest_index) {
+    if (dest_table) d.data = dest_table[dest_index];           // destination resolved on the device (graph replay with a moving KV position)
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
         const int64_t a0 = i % a.ne[0], ar = i / a.ne[0], a1 = ar % a.ne[1], ar2 = ar / a.ne[1], a2 = ar2 % a.ne[2], a3 = ar2 / a.ne[2];
         const int64_t d0 = i % d.ne[0], dr = i / d.ne[0], d1 = dr % d.ne[1], dr2 = dr / d.ne[1], d2 = dr2 % d.ne[2], d3 = dr2 / d.ne[2];
@@ -285,8 +286,45 @@ int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * str
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 / f16 only");
     const int64_t n = nelements(dst);
     if (n == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n);
+    hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n, (char * const *) nullptr, 0);
     OPS_LAUNCHED();
+}
+
+int mi355q_op_cpy_indirect(const mi355q_tensor * a, const mi355q_tensor * dst, void * const * dest_table, int index, void * stream) {
+    if (!a || !dst || !dest_table || index < 0 || nelements(a) != nelements(dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_cpy_indirect: arguments");
+    if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 / f16 only");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n, (char * const *) dest_table, index);
+    OPS_LAUNCHED();
+}
+
+struct mi355q_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int mi355q_graph_capture_begin(void * stream) {
+    if (hipStreamBeginCapture((hipStream_t) stream, hipStreamCaptureModeThreadLocal) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "graph_capture_begin failed");
+    return MI355Q_OK;
+}
+int mi355q_graph_capture_end(void * stream, mi355q_graph ** out) {
+    if (out) *out = nullptr;
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture((hipStream_t) stream, &g) != hipSuccess || !g) { (void) hipGetLastError(); OPS_FAIL(MI355Q_ERR_HIP, "graph_capture_end: capture failed"); }
+    hipGraphExec_t e = nullptr;
+    if (hipGraphInstantiate(&e, g, nullptr, nullptr, 0) != hipSuccess || !e) { (void) hipGraphDestroy(g); (void) hipGetLastError(); OPS_FAIL(MI355Q_ERR_HIP, "graph_capture_end: instantiate failed"); }
+    if (!out) { (void) hipGraphExecDestroy(e); (void) hipGraphDestroy(g); return MI355Q_OK; }
+    *out = new mi355q_graph{ g, e };
+    return MI355Q_OK;
+}
+int mi355q_graph_launch(mi355q_graph * graph, void * stream) {
+    if (!graph) OPS_FAIL(MI355Q_ERR_SHAPE, "graph_launch: null graph");
+    if (hipGraphLaunch(graph->exec, (hipStream_t) stream) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "graph_launch failed");
+    return MI355Q_OK;
+}
+int mi355q_graph_destroy(mi355q_graph * graph) {
+    if (!graph) return MI355Q_OK;
+    (void) hipGraphExecDestroy(graph->exec); (void) hipGraphDestroy(graph->graph);
+    delete graph;
+    return MI355Q_OK;
 }
 
 int mi355q_op_soft_max(const mi355q_tensor * a, const mi355q_tensor * mask, const mi355q_tensor * dst, float scale, float max_bias, void * stream) {

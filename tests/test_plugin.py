@@ -110,3 +110,31 @@ def test_decode_layer_resident_and_equal_to_cpu(n_tokens):
     print(r.stdout[-1500:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 refused by MI355_0" in r.stdout and "LAYER PARITY OK" in r.stdout
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("no_graphs", [False, True])
+def test_decode_loop_launch_graph_replay(no_graphs):
+    """A 40-token decode loop over that layer (a fresh ggml graph per token, activations placed by ggml_gallocr, the KV store
+    position advancing every token and the padded attention window growing 32 -> 64): every step must equal the CPU backend,
+    and -- unless MI355_NO_GRAPHS is set -- most steps must have been replays of a captured launch graph (the K/V store
+    destinations reach the captured copy kernels through the device-side pointer table)."""
+    exe = _harness().parent / "layer_parity"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/*/layer_parity not built")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN), MI355_GRAPH_STATS="1")
+    if no_graphs:
+        env["MI355_NO_GRAPHS"] = "1"
+    r = subprocess.run([str(exe), "1", "MI355_0", "small", "40"], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:], r.stderr[-500:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "LAYER PARITY OK" in r.stdout
+    m = re.search(r"graph_compute calls: (\d+) eager, (\d+) captured, (\d+) replayed", r.stderr)
+    assert m, r.stderr[-2000:]
+    eager, captured, replayed = map(int, m.groups())
+    assert eager + captured + replayed == 40
+    if no_graphs:
+        assert captured == 0 and replayed == 0
+    else:
+        assert captured >= 2 and replayed >= 30      # two window sizes (n_kv 32 and 64), each: 1 eager + 1 capture + replays
