@@ -23,6 +23,9 @@ bool mmq_supported(int type, int64_t k);
 size_t mmq_workspace(int64_t n, int64_t k);
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
                     int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream);
+bool mmq_i8_supported(int type, int64_t k);
+int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
+                  int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream);
 
 // tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
 static bool use_mmq(int type, int64_t n, int64_t k, int flags) {
@@ -220,8 +223,14 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
         bool ok = workspace && workspace_bytes >= mmq_workspace(n, k);
         for (int i = 0; i < n_mats && ok; ++i) ok = mmq_supported(mats[i].type, k) && !(((uintptr_t) mats[i].y | (uintptr_t) mats[i].y_stride) & 15);
         if (ok) {
-            for (int i = 0; i < n_mats; ++i)
-                MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st));
+            // Q4_K: integer matrix cores on Q8_K-quantized activations (the CPU backend's arithmetic); the other planar types: bf16 tier
+            static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
+            for (int i = 0; i < n_mats; ++i) {
+                if (!no_i8 && mmq_i8_supported(mats[i].type, k) && !(((uintptr_t) x | (uintptr_t) x_stride) & 15))
+                    MQ_TRY(launch_mmq_i8(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st));
+                else
+                    MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st));
+            }
             return MI355Q_OK;
         }
     }

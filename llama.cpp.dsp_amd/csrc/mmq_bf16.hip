@@ -299,7 +299,11 @@ bool mmq_supported(int type, int64_t k) {
     }
 }
 
-size_t mmq_workspace(int64_t n, int64_t k) { return (size_t) (n * k * 2 + 255) & ~(size_t) 255; }
+size_t mmq_i8_workspace(int64_t n, int64_t k);
+size_t mmq_workspace(int64_t n, int64_t k) {                  // one scratch size for both MFMA tiers: bf16 activations, or the int8 image of mmq_i8.hip
+    const size_t a = (size_t) (n * k * 2 + 255) & ~(size_t) 255, b = k % 256 == 0 ? mmq_i8_workspace(n, k) : 0;
+    return a > b ? a : b;
+}
 
 // w: planar device rows; x f32 [n][k] (row stride x_stride); workspace >= mmq_workspace(n,k); y f32 [n][m] (y_stride % 16 == 0)
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,

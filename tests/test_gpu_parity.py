@@ -262,7 +262,15 @@ def test_mfma_tier(G, torch, orc, t, shape):
     # (2) against the exact product of the dequantized weights and the f32 activations (float64)
     exact = x.astype(np.float64) @ orc.dequantize(t, w, K).astype(np.float64).T
     e = nmse(y, exact)
-    assert e <= 2e-5, f"NMSE vs exact {e:.3e}"
+    if t == oracle.Q4_K:
+        # integer tier (csrc/mmq_i8.hip): the CPU's own arithmetic -- Q8_K activations, exact integer block sums -- so it matches the
+        # oracle to f32 summation order, and its distance from the exact product is the CPU's Q8_K quantization noise (~5e-5)
+        check_close(y[np.ix_(cols, rows)], ref)
+        assert e <= 1.5e-4, f"NMSE vs exact {e:.3e}"
+        e_cpu = nmse(ref, exact[np.ix_(cols, rows)])
+        assert e <= 3 * e_cpu + 1e-6, f"NMSE vs exact {e:.3e}, the CPU arithmetic itself {e_cpu:.3e}"
+    else:
+        assert e <= 2e-5, f"NMSE vs exact {e:.3e}"
     # (3) the GEMV tier forced on the same data agrees with the oracle to f32 summation order
     if N <= 64:
         yg = gpu_mul_mat(G, torch, t, w, x, M, K, flags=0x4)          # MI355Q_FLAG_FORCE_GEMV
@@ -279,7 +287,7 @@ def test_mfma_tier_ragged_and_alignment_fallback(G, torch, orc):
         x = rng.standard_normal((N, K)).astype(np.float32)
         y = gpu_mul_mat(G, torch, t, w, x, M, K)
         ref = orc.mul_mat(t, w, x, M, N, K)
-        assert nmse(y, ref) <= 5e-4
+        check_close(y, ref, f"ragged {M}x{N}")                         # Q4_K: the integer tier reproduces the CPU arithmetic
     M, N = 131, 20                                                      # 131*4 bytes per row: not 16-byte aligned
     w = quantized_weights(t, M, K, rng); x = rng.standard_normal((N, K)).astype(np.float32)
     check_close(gpu_mul_mat(G, torch, t, w, x, M, K), orc.mul_mat(t, w, x, M, N, K))
