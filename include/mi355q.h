@@ -233,6 +233,14 @@ typedef struct mi355q_tensor {
 int mi355q_op_bin_bcast(int op, const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);
 int mi355q_op_unary(int uop, const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
 int mi355q_op_rms_norm(const mi355q_tensor *a, const mi355q_tensor *dst, float eps, void *stream);
+/* Fusions around the path (the reference's graph emits them as separate nodes: build_norm = RMS_NORM then MUL,
+ * src/llama-graph.cpp; build_ffn LLM_FFN_SILU + LLM_FFN_PAR = UNARY then MUL).  Same f32 operations in the same order as the
+ * separate ops, so results are bit-identical to issuing the nodes one by one.
+ *   add_rms_norm_mul: x = b ? a + b : a;  if (sum) *sum = x;  dst = rms_norm(x, eps) [* weight[ne0]]     (b, sum, weight may be NULL)
+ *   unary_mul:        dst = unary(a) * b          (SiLU / ReLU / sigmoid; contiguous f32 tensors of one shape)                  */
+int mi355q_op_add_rms_norm_mul(const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *sum, const float *weight,
+                               const mi355q_tensor *dst, float eps, void *stream);
+int mi355q_op_unary_mul(int uop, const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);
 int mi355q_op_cpy(const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
 int mi355q_op_soft_max(const mi355q_tensor *a, const mi355q_tensor *mask, const mi355q_tensor *dst, float scale, float max_bias, void *stream);
 typedef struct mi355q_rope_params {      /* the op_params of GGML_OP_ROPE (ggml.c ggml_rope_impl) */

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #define MI355_MAX_DEVICES 16
@@ -67,6 +68,7 @@ struct mi355_backend_ctx {
     std::vector<void *> dest_host;
     bool        capturing = false;
     long        n_eager = 0, n_captured = 0, n_replayed = 0;   // graph_compute calls by how they ran (MI355_GRAPH_STATS=1 prints them)
+    long        n_fused_norm = 0, n_fused_mats = 0, n_fused_act = 0, n_elided_cont = 0;   // launches saved by the fusions of mi355_issue_nodes
 };
 constexpr int MI355_MAX_CPY_DESTS = 4096;
 
@@ -222,7 +224,8 @@ static void * mi355_workspace(mi355_backend_ctx * ctx, size_t bytes) {
 
 // GGML_OP_MUL_MAT (ggml.c:2730-2745; CPU semantics ggml-cpu.c:1266-1458): dst[ne01, ne11, ne12, ne13],
 // src0 broadcast over dims 2/3 with r2 = ne12/ne02, r3 = ne13/ne03.
-static void mi355_mul_mat(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
+// x_alias: read the activations from this (flat-contiguous) buffer instead of src1->data -- an elided CONT (mi355_issue_nodes)
+static void mi355_mul_mat(mi355_backend_ctx * ctx, struct ggml_tensor * dst, const void * x_alias = nullptr) {
     const struct ggml_tensor * src0 = dst->src[0];
     const struct ggml_tensor * src1 = dst->src[1];
     const int64_t K = src0->ne[0], M = src0->ne[1], N = src1->ne[1];
@@ -232,7 +235,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, struct ggml_tensor * dst) {
     for (int64_t i13 = 0; i13 < src1->ne[3]; ++i13) {
         for (int64_t i12 = 0; i12 < src1->ne[2]; ++i12) {
             const char * w = (const char *) src0->data + (i12 / r2) * src0->nb[2] + (i13 / r3) * src0->nb[3];
-            const char * x = (const char *) src1->data + i12 * src1->nb[2] + i13 * src1->nb[3];
+            const char * x = (const char *) (x_alias ? x_alias : src1->data) + i12 * src1->nb[2] + i13 * src1->nb[3];
             char *       y = (char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3];
             MQ_CHECK(mi355q_mul_mat((int) src0->type, w, (int64_t) src0->nb[1], (const float *) x, (int64_t) src1->nb[1],
                                     (float *) y, (int64_t) dst->nb[1], M, N, K, wsp, ws, 0, ctx->stream));
@@ -264,7 +267,11 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355q_set_device(ctx->device);
     if (ctx->stream) { mi355q_stream_synchronize(ctx->stream); mi355q_stream_destroy(ctx->stream); }
     if (ctx->workspace) mi355q_free(ctx->workspace);
-    if (getenv("MI355_GRAPH_STATS")) fprintf(stderr, "MI355 graph_compute calls: %ld eager, %ld captured, %ld replayed\n", ctx->n_eager, ctx->n_captured, ctx->n_replayed);
+    if (getenv("MI355_GRAPH_STATS")) {
+        fprintf(stderr, "MI355 graph_compute calls: %ld eager, %ld captured, %ld replayed\n", ctx->n_eager, ctx->n_captured, ctx->n_replayed);
+        fprintf(stderr, "MI355 fusions (launches saved while issuing nodes): %ld norm*weight, %ld joined matmuls, %ld act*mul, %ld elided CONT\n",
+                ctx->n_fused_norm, ctx->n_fused_mats, ctx->n_fused_act, ctx->n_elided_cont);
+    }
     if (ctx->graph) mi355q_graph_destroy(ctx->graph);
     if (ctx->dest_table) mi355q_free(ctx->dest_table);
     delete ctx;
@@ -376,24 +383,176 @@ static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph) {
     return h;
 }
 
+// ---- fusions around the path ---------------------------------------------------------------------------------
+// A decode step is ~23 tiny dependent launches per llama layer and each costs ~6-8 us of dispatch latency whatever its size (a
+// captured launch graph does not remove that: profiles/round1_plugin_layer.md), so the lever is FEWER launches.  While issuing the
+// nodes the backend joins what the reference's graph builder emits as separate nodes:
+//   RMS_NORM -> MUL(weight)                    one kernel                       (build_norm, src/llama-graph.cpp)
+//   MUL_MATs on the same activations           one multi-matrix GEMV launch     (wq/wk/wv, ffn_gate/ffn_up; N <= 8)
+//   UNARY(SiLU) -> MUL(up)                     one kernel                       (build_ffn LLM_FFN_SILU / LLM_FFN_PAR)
+//   CONT of an already flat tensor -> MUL_MAT  the copy is skipped, the matmul reads the source
+// Every fused form performs the same f32 operations in the same order as the separate nodes (results bit-identical, checked by
+// tests/test_plugin.py with MI355_NO_FUSION=1 against the default).  A node issued EARLIER than its position in the graph (a joined
+// matmul, a fused MUL) writes its output early: it is only done when no node it jumps over reads or writes memory overlapping that
+// output (the graph allocator reuses freed tensors' memory) and all its inputs are already computed.
+static bool mi355_is_view_op(const struct ggml_tensor * t) {
+    return t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE;
+}
+static bool mi355_overlap(const struct ggml_tensor * a, const struct ggml_tensor * b) {
+    if (!a || !b || !a->data || !b->data) return false;
+    const char * a0 = (const char *) a->data, * b0 = (const char *) b->data;
+    return a0 < b0 + ggml_nbytes(b) && b0 < a0 + ggml_nbytes(a);
+}
+static bool mi355_flat_contiguous(const struct ggml_tensor * t) {      // memory order == logical order (dims of size 1 may carry any stride)
+    size_t expect = ggml_type_size(t->type);
+    if (ggml_blck_size(t->type) != 1) return false;
+    for (int d = 0; d < GGML_MAX_DIMS; ++d) { if (t->ne[d] != 1 && t->nb[d] != expect) return false; expect *= (size_t) t->ne[d]; }
+    return true;
+}
+
+struct mi355_fuser {
+    struct ggml_cgraph * g;
+    std::unordered_map<const struct ggml_tensor *, int> uses, producer;
+    std::vector<char> done;
+    explicit mi355_fuser(struct ggml_cgraph * cgraph) : g(cgraph), done((size_t) cgraph->n_nodes, 0) {
+        for (int i = 0; i < g->n_nodes; ++i) {
+            producer[g->nodes[i]] = i;
+            for (int j = 0; j < GGML_MAX_SRC; ++j) if (g->nodes[i]->src[j]) ++uses[g->nodes[i]->src[j]];
+        }
+    }
+    bool single_use(const struct ggml_tensor * t) const {
+        if (t->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
+        auto it = uses.find(t); return it != uses.end() && it->second == 1;
+    }
+    // is t (through its view chain) computed once everything before node i and the nodes marked done have been issued?
+    bool ready_before(const struct ggml_tensor * t, int i) const {
+        for (; t; t = t->view_src) {
+            auto it = producer.find(t);
+            if (it != producer.end() && it->second >= i && !done[(size_t) it->second] && !mi355_is_view_op(t)) return false;
+        }
+        return true;
+    }
+    // may node j be issued at position i < j?  (`self`: the node at i that the fused kernel computes on the fly)
+    bool can_issue_early(int i, int j, const struct ggml_tensor * self = nullptr) const {
+        const struct ggml_tensor * nj = g->nodes[j];
+        for (int s = 0; s < GGML_MAX_SRC; ++s) if (nj->src[s] && nj->src[s] != self && !ready_before(nj->src[s], i)) return false;
+        for (int k = i; k < j; ++k) {
+            const struct ggml_tensor * nk = g->nodes[k];
+            if (done[(size_t) k] || mi355_is_view_op(nk) || ggml_is_empty(nk) || nk == self) continue;
+            if (mi355_overlap(nk, nj)) return false;
+            for (int s = 0; s < GGML_MAX_SRC; ++s) if (mi355_overlap(nk->src[s], nj)) return false;
+        }
+        return true;
+    }
+    int next_compute(int i) const {                               // the next node after i that launches something (-1: none)
+        for (int k = i + 1; k < g->n_nodes; ++k) if (!mi355_is_view_op(g->nodes[k]) && !ggml_is_empty(g->nodes[k])) return done[(size_t) k] ? -1 : k;
+        return -1;
+    }
+};
+
+static bool mi355_joinable_mat(const struct ggml_tensor * n) {
+    if (n->op != GGML_OP_MUL_MAT || !mi355_is_quant(n->src[0]->type)) return false;
+    const struct ggml_tensor * w = n->src[0], * x = n->src[1];
+    return x->type == GGML_TYPE_F32 && x->ne[1] <= 8 && x->ne[2] == 1 && x->ne[3] == 1 && w->ne[2] == 1 && w->ne[3] == 1 &&
+           mi355q_weights_are_planar((int) w->type, w->ne[0]) == 1;
+}
+
 static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_cgraph * cgraph) {
+    static const bool no_fusion = getenv("MI355_NO_FUSION") != nullptr;
+    const bool fuse = !no_fusion && cgraph->n_nodes >= 4;
+    mi355_fuser * fz = fuse ? new mi355_fuser(cgraph) : nullptr;
+    struct fz_guard { mi355_fuser * p; ~fz_guard() { delete p; } } guard{ fz };
     int cpy_index = 0;
     for (int i = 0; i < cgraph->n_nodes; ++i) {
         struct ggml_tensor * node = cgraph->nodes[i];
         if (ggml_is_empty(node)) continue;
+        if (node->op == GGML_OP_CPY) ++cpy_index;                 // (CPY nodes are never fused: their table slot is their ordinal)
+        if (fz && fz->done[(size_t) i]) continue;
         switch (node->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             break;
         case GGML_OP_MUL_MAT:
-            if (mi355_is_quant(node->src[0]->type)) mi355_mul_mat(ctx, node); else mi355_glue_op(ctx, node);
+            if (!mi355_is_quant(node->src[0]->type)) { mi355_glue_op(ctx, node); break; }
+            if (fz && mi355_joinable_mat(node)) {                 // other matmuls on the same activations (at most 4 per launch)
+                int idx[4] = { i, -1, -1, -1 }, n = 1;
+                for (int j = i + 1; j < cgraph->n_nodes && j <= i + 24 && n < 4; ++j) {
+                    const struct ggml_tensor * o = cgraph->nodes[j];
+                    if (fz->done[(size_t) j] || !mi355_joinable_mat(o) || o->src[1] != node->src[1] || o->src[0]->ne[0] != node->src[0]->ne[0] ||
+                        mi355q_act_type((int) o->src[0]->type) != mi355q_act_type((int) node->src[0]->type)) continue;   // one activation format per launch
+                    bool ok = fz->can_issue_early(i, j);
+                    for (int q = 1; q < n && ok; ++q) ok = !mi355_overlap(cgraph->nodes[idx[q]], o);
+                    if (ok) idx[n++] = j;
+                }
+                if (n > 1) {
+                    mi355q_mat mats[4];
+                    for (int q = 0; q < n; ++q) {
+                        const struct ggml_tensor * o = cgraph->nodes[idx[q]];
+                        mats[q].type = (int) o->src[0]->type; mats[q].w = o->src[0]->data; mats[q].w_stride = (int64_t) o->src[0]->nb[1];
+                        mats[q].y = (float *) o->data; mats[q].y_stride = (int64_t) o->nb[1]; mats[q].m = o->src[0]->ne[1];
+                    }
+                    const struct ggml_tensor * x = node->src[1];
+                    MQ_CHECK(mi355q_mul_mat_multi(mats, n, (const float *) x->data, (int64_t) x->nb[1], x->ne[1], x->ne[0], nullptr, 0, 0, ctx->stream));
+                    for (int q = 1; q < n; ++q) fz->done[(size_t) idx[q]] = 1;
+                    ctx->n_fused_mats += n - 1;
+                    break;
+                }
+            }
+            mi355_mul_mat(ctx, node);
             break;
         case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
         case GGML_OP_CPY:
-            mi355_glue_op(ctx, node, ctx->dest_table && cpy_index < MI355_MAX_CPY_DESTS ? cpy_index : -1);
-            ++cpy_index;
+            mi355_glue_op(ctx, node, ctx->dest_table && cpy_index - 1 < MI355_MAX_CPY_DESTS ? cpy_index - 1 : -1);
             break;
-        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_UNARY: case GGML_OP_RMS_NORM:
-        case GGML_OP_CONT: case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
+        case GGML_OP_RMS_NORM: {
+            const int j = fz ? fz->next_compute(i) : -1;          // RMS_NORM -> MUL by a [ne0] weight vector
+            if (j >= 0 && cgraph->nodes[j]->op == GGML_OP_MUL && fz->single_use(node) && node->type == GGML_TYPE_F32 && node->nb[0] == 4) {
+                struct ggml_tensor * mul = cgraph->nodes[j];
+                const struct ggml_tensor * w = mul->src[0] == node ? mul->src[1] : (mul->src[1] == node ? mul->src[0] : nullptr);
+                if (w && w != node && w->type == GGML_TYPE_F32 && ggml_is_contiguous(w) && w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] &&
+                    ggml_are_same_shape(mul, node) && mul->nb[0] == 4 && node->src[0]->nb[0] == 4 && fz->ready_before(w, i)) {
+                    float eps; memcpy(&eps, node->op_params, sizeof(float));
+                    const mi355q_tensor a = mi355_td(node->src[0]), d = mi355_td(mul);
+                    MQ_CHECK(mi355q_op_add_rms_norm_mul(&a, nullptr, nullptr, (const float *) w->data, &d, eps, ctx->stream));
+                    fz->done[(size_t) j] = 1; ++ctx->n_fused_norm;
+                    break;
+                }
+            }
+            mi355_glue_op(ctx, node);
+        } break;
+        case GGML_OP_UNARY: {
+            const int uop = mi355_unary_code(ggml_get_unary_op(node));
+            if (fz && (uop == MI355Q_UNARY_SILU || uop == MI355Q_UNARY_RELU || uop == MI355Q_UNARY_SIGMOID) && fz->single_use(node) &&
+                node->type == GGML_TYPE_F32 && ggml_is_contiguous(node) && ggml_is_contiguous(node->src[0])) {
+                int j = -1;                                       // the MUL that consumes it, a few nodes on (ffn_up's matmul sits in between)
+                for (int k = i + 1; k < cgraph->n_nodes && k <= i + 8; ++k)
+                    if (cgraph->nodes[k]->op == GGML_OP_MUL && (cgraph->nodes[k]->src[0] == node || cgraph->nodes[k]->src[1] == node)) { j = k; break; }
+                if (j >= 0 && !fz->done[(size_t) j]) {
+                    struct ggml_tensor * mul = cgraph->nodes[j];
+                    const struct ggml_tensor * o = mul->src[0] == node ? mul->src[1] : mul->src[0];
+                    if (o != node && o->type == GGML_TYPE_F32 && ggml_is_contiguous(o) && ggml_are_same_shape(o, node) && ggml_are_same_shape(mul, node) &&
+                        ggml_is_contiguous(mul) && fz->can_issue_early(i, j, node)) {
+                        const mi355q_tensor a = mi355_td(node->src[0]), b = mi355_td(o), d = mi355_td(mul);
+                        MQ_CHECK(mi355q_op_unary_mul(uop, &a, &b, &d, ctx->stream));
+                        fz->done[(size_t) j] = 1; ++ctx->n_fused_act;
+                        break;
+                    }
+                }
+            }
+            mi355_glue_op(ctx, node);
+        } break;
+        case GGML_OP_CONT: {
+            const int j = fz ? fz->next_compute(i) : -1;          // CONT of a flat tensor feeding a quantized matmul: no copy
+            if (j >= 0 && cgraph->nodes[j]->op == GGML_OP_MUL_MAT && cgraph->nodes[j]->src[1] == node && mi355_is_quant(cgraph->nodes[j]->src[0]->type) &&
+                fz->single_use(node) && node->type == GGML_TYPE_F32 && node->src[0]->type == GGML_TYPE_F32 && mi355_flat_contiguous(node->src[0]) &&
+                ggml_is_contiguous(node) && !mi355_overlap(cgraph->nodes[j], node->src[0]) && ((uintptr_t) node->src[0]->data & 15) == 0) {
+                mi355_mul_mat(ctx, cgraph->nodes[j], node->src[0]->data);
+                fz->done[(size_t) j] = 1; ++ctx->n_elided_cont;
+                break;
+            }
+            mi355_glue_op(ctx, node);
+        } break;
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
+        case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
             mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));

@@ -85,24 +85,57 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
-// ---- RMS_NORM: one wave per row -----------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rms_norm(const TensorD a, const TensorD d, float eps, int64_t nrows) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= nrows) return;
+// ---- RMS_NORM, optionally fused with a preceding ADD and a following MUL by a weight vector -------------------
+// One 256-thread workgroup per row (a decode step has ONE row of n_embd elements: a single wave walking it exposes a memory round
+// trip per 64 elements).  The f32 operations and their order are those of the separate ADD, RMS_NORM and MUL nodes, so the fused
+// forms are bit-identical to issuing the nodes one by one; the sum of squares is accumulated in f64 as the CPU's ggml_float does
+// (ops.cpp ggml_compute_forward_rms_norm_f32).  b / sum / w may be absent.
+__global__ void __launch_bounds__(256) k_add_rms_norm_mul(const TensorD a, const TensorD b, int has_b, const TensorD sum, int has_sum,
+                                                          const float * __restrict__ w, const TensorD d, float eps) {
+    __shared__ double part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
     const int64_t i1 = row % a.ne[1], r2 = row / a.ne[1], i2 = r2 % a.ne[2], i3 = r2 / a.ne[2];
     const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    const float * xb = has_b ? (const float *) (b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3]) : nullptr;
+    float * xs = has_sum ? (float *) (sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]) : nullptr;
     float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
     const int64_t n = a.ne[0];
     double s = 0.0;
-    for (int64_t i = lane; i < n; i += 64) s += (double) __fmul_rn(x[i], x[i]);       // (ggml_float)(x*x): the square is rounded to f32 first
+#pragma unroll 4
+    for (int64_t i = tid; i < n; i += 256) {
+        const float v = has_b ? __fadd_rn(x[i], xb[i]) : x[i];
+        if (has_sum) xs[i] = v;
+        s += (double) __fmul_rn(v, v);                            // (ggml_float)(x*x): the square is rounded to f32 first
+    }
     s = wave_sum_f64(s);
-    const float mean = (float) (s / (double) n);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    s = (part[0] + part[1]) + (part[2] + part[3]);
+    const float mean  = (float) (s / (double) n);
     // 1.0f / sqrtf(mean + eps) with BOTH roundings of the CPU: the compiler folds the f32 form into v_rsq_f32 (1 ulp off in ~20 % of
     // rows) whatever intrinsics spell it, so each step is done in f64 and rounded to f32
     const float root  = (float) sqrt((double) __fadd_rn(mean, eps));
     const float scale = (float) (1.0 / (double) root);
-    for (int64_t i = lane; i < n; i += 64) y[i] = __fmul_rn(x[i], scale);
+#pragma unroll 4
+    for (int64_t i = tid; i < n; i += 256) {
+        const float v = has_b ? __fadd_rn(x[i], xb[i]) : x[i];
+        const float t = __fmul_rn(v, scale);
+        y[i] = w ? __fmul_rn(t, w[i]) : t;
+    }
+}
+
+// ---- fused UNARY * other (SiLU(gate) * up): contiguous f32 tensors of one shape ---------------------------------
+template <int OP>
+__global__ void __launch_bounds__(256) k_unary_mul(const float * __restrict__ a, const float * __restrict__ b, float * __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const float x = a[i];
+        float v;
+        if constexpr (OP == MI355Q_UNARY_SILU)         v = __fdiv_rn(x, 1.0f + expf(-x));
+        else if constexpr (OP == MI355Q_UNARY_RELU)    v = x > 0.0f ? x : 0.0f;
+        else                                           v = __fdiv_rn(1.0f, 1.0f + expf(-x));
+        d[i] = __fmul_rn(v, b[i]);
+    }
 }
 
 // ---- CPY / CONT / DUP: logical element order, any strides, f32 <-> f16 -------------------------------------
@@ -136,9 +169,11 @@ __global__ void __launch_bounds__(256) k_soft_max(const TensorD a, const TensorD
         return v;
     };
     float mx = -INFINITY;
+#pragma unroll 8
     for (int64_t i = lane; i < nc; i += 64) mx = fmaxf(mx, val(i));
     mx = wave_max_f32(mx);
     double sum = 0.0;
+#pragma unroll 8
     for (int64_t i = lane; i < nc; i += 64) {
         const float e = expf(__fsub_rn(val(i), mx));
         dp[i] = e;
@@ -146,6 +181,7 @@ __global__ void __launch_bounds__(256) k_soft_max(const TensorD a, const TensorD
     }
     sum = wave_sum_f64(sum);
     const float inv = (float) (1.0 / sum);
+#pragma unroll 8
     for (int64_t i = lane; i < nc; i += 64) dp[i] = __fmul_rn(dp[i], inv);
 }
 
@@ -277,7 +313,38 @@ int mi355q_op_rms_norm(const mi355q_tensor * a, const mi355q_tensor * dst, float
     if (a->nb[0] != 4 || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_rms_norm: rows must be contiguous");
     const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
     if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_rms_norm, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), eps, nrows);
+    hipLaunchKernelGGL(k_add_rms_norm_mul, dim3((unsigned) nrows), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(a), 0, to_d(a), 0, (const float *) nullptr, to_d(dst), eps);
+    OPS_LAUNCHED();
+}
+
+static bool contiguous_f32(const mi355q_tensor * t) {
+    return t->type == 0 && t->nb[0] == 4 && t->nb[1] == 4 * t->ne[0] && t->nb[2] == t->nb[1] * t->ne[1] && t->nb[3] == t->nb[2] * t->ne[2];
+}
+
+int mi355q_op_add_rms_norm_mul(const mi355q_tensor * a, const mi355q_tensor * b, const mi355q_tensor * sum, const float * weight,
+                               const mi355q_tensor * dst, float eps, void * stream) {
+    if (!a || !dst || !same_shape(a, dst) || a->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_add_rms_norm_mul: f32 tensors of one shape");
+    if ((b && (!same_shape(a, b) || b->type != 0)) || (sum && (!b || !same_shape(a, sum) || sum->type != 0))) OPS_FAIL(MI355Q_ERR_SHAPE, "op_add_rms_norm_mul: addend / sum shape");
+    if (a->nb[0] != 4 || dst->nb[0] != 4 || (b && b->nb[0] != 4) || (sum && sum->nb[0] != 4)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_add_rms_norm_mul: rows must be contiguous");
+    const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
+    if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_add_rms_norm_mul, dim3((unsigned) nrows), dim3(256), 0, (hipStream_t) stream, to_d(a), b ? to_d(b) : to_d(a), b ? 1 : 0,
+                       sum ? to_d(sum) : to_d(a), sum ? 1 : 0, weight, to_d(dst), eps);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_unary_mul(int uop, const mi355q_tensor * a, const mi355q_tensor * b, const mi355q_tensor * dst, void * stream) {
+    if (!a || !b || !dst || !same_shape(a, dst) || !same_shape(b, dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_unary_mul: shapes differ");
+    if (!contiguous_f32(a) || !contiguous_f32(b) || !contiguous_f32(dst)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_unary_mul: contiguous f32 tensors only");
+    const int64_t n = nelements(dst);
+    if (n == 0) return MI355Q_OK;
+    const dim3 g(grid_for(n)), t(256);
+#define U(OPV) case OPV: hipLaunchKernelGGL(k_unary_mul<OPV>, g, t, 0, (hipStream_t) stream, (const float *) a->data, (const float *) b->data, (float *) dst->data, n); break;
+    switch (uop) {
+    U(MI355Q_UNARY_SILU) U(MI355Q_UNARY_RELU) U(MI355Q_UNARY_SIGMOID)
+    default: OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_unary_mul: SiLU / ReLU / sigmoid only");
+    }
+#undef U
     OPS_LAUNCHED();
 }
 

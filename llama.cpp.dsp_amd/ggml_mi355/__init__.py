@@ -56,6 +56,7 @@ ABI_SYMBOLS = [
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
     "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale", "mi355q_op_cpy_indirect",
     "mi355q_graph_capture_begin", "mi355q_graph_capture_end", "mi355q_graph_launch", "mi355q_graph_destroy",
+    "mi355q_op_add_rms_norm_mul", "mi355q_op_unary_mul",
 ]
 
 
@@ -127,6 +128,8 @@ def lib() -> C.CDLL:
     L.mi355q_op_unary.argtypes = [i32, TP, TP, vp]
     L.mi355q_op_rms_norm.argtypes = [TP, TP, C.c_float, vp]
     L.mi355q_op_cpy.argtypes = [TP, TP, vp]
+    L.mi355q_op_add_rms_norm_mul.argtypes = [TP, TP, TP, vp, TP, C.c_float, vp]
+    L.mi355q_op_unary_mul.argtypes = [i32, TP, TP, TP, vp]
     L.mi355q_op_soft_max.argtypes = [TP, TP, TP, C.c_float, C.c_float, vp]
     L.mi355q_op_rope.argtypes = [TP, vp, vp, TP, C.POINTER(_RopeParams), vp]
     L.mi355q_op_mul_mat_f.argtypes = [TP, TP, TP, vp]
@@ -343,6 +346,26 @@ def op_rms_norm(a, eps: float, out=None):
     torch = _torch()
     out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
     _check(lib().mi355q_op_rms_norm(C.byref(_td(a)), C.byref(_td(out)), eps, _stream(torch)), "op_rms_norm")
+    return out
+
+
+def op_add_rms_norm_mul(a, eps: float, b=None, weight=None, want_sum: bool = False):
+    """Fused [a + b ->] rms_norm [-> * weight]; returns out or (out, sum).  Bit-identical to the separate ops (include/mi355q.h)."""
+    torch = _torch()
+    out = torch.empty_like(a, memory_format=torch.contiguous_format)
+    s = torch.empty_like(a, memory_format=torch.contiguous_format) if (want_sum and b is not None) else None
+    if weight is not None and (weight.dtype != torch.float32 or not weight.is_contiguous() or weight.numel() != a.shape[-1]):
+        raise ValueError("weight must be a contiguous f32 vector of the row length")
+    _check(lib().mi355q_op_add_rms_norm_mul(C.byref(_td(a)), C.byref(_td(b)) if b is not None else None, C.byref(_td(s)) if s is not None else None,
+                                            weight.data_ptr() if weight is not None else None, C.byref(_td(out)), eps,
+                                            _stream(torch)), "op_add_rms_norm_mul")
+    return (out, s) if s is not None else out
+
+
+def op_unary_mul(uop: int, a, b):
+    torch = _torch()
+    out = torch.empty_like(a, memory_format=torch.contiguous_format)
+    _check(lib().mi355q_op_unary_mul(uop, C.byref(_td(a)), C.byref(_td(b)), C.byref(_td(out)), _stream(torch)), "op_unary_mul")
     return out
 
 

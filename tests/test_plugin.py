@@ -138,3 +138,31 @@ def test_decode_loop_launch_graph_replay(no_graphs):
         assert captured == 0 and replayed == 0
     else:
         assert captured >= 2 and replayed >= 30      # two window sizes (n_kv 32 and 64), each: 1 eager + 1 capture + replays
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("n_tokens", [1, 3])
+def test_fused_nodes_bit_identical_to_separate_nodes(n_tokens):
+    """The launch-saving fusions of graph_compute (RMS_NORM*weight in one kernel, matmuls on the same activations in one launch,
+    SiLU*up in one kernel; ggml-mi355.cpp mi355_issue_nodes) must not change a single output bit: the decode loop's digest of every
+    step's layer output and of the final KV cache is compared between the default and MI355_NO_FUSION=1, and the fusions must
+    actually have happened in the default run."""
+    exe = _harness().parent / "layer_parity"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/*/layer_parity not built")
+    digests, saved = [], []
+    for no_fusion in (False, True):
+        env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN), MI355_GRAPH_STATS="1")
+        if no_fusion:
+            env["MI355_NO_FUSION"] = "1"
+        r = subprocess.run([str(exe), str(n_tokens), "MI355_0", "small", "12"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "LAYER PARITY OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        digests.append(re.search(r"device output digest ([0-9a-f]{16})", r.stdout).group(1))
+        m = re.search(r"fusions .*: (\d+) norm\*weight, (\d+) joined matmuls, (\d+) act\*mul, (\d+) elided CONT", r.stderr)
+        assert m, r.stderr[-2000:]
+        saved.append(tuple(map(int, m.groups())))
+    print("launches saved (norm*weight, joined matmuls, act*mul, elided CONT):", saved[0])
+    assert digests[0] == digests[1], digests
+    assert saved[1] == (0, 0, 0, 0)
+    assert saved[0][0] > 0 and saved[0][1] > 0 and saved[0][2] > 0
