@@ -68,7 +68,7 @@ struct mi355_backend_ctx {
     std::vector<void *> dest_host;
     bool        capturing = false;
     long        n_eager = 0, n_captured = 0, n_replayed = 0;   // graph_compute calls by how they ran (MI355_GRAPH_STATS=1 prints them)
-    long        n_fused_norm = 0, n_fused_mats = 0, n_fused_act = 0, n_elided_cont = 0;   // launches saved by the fusions of mi355_issue_nodes
+    long        n_fused_norm = 0, n_fused_mats = 0, n_fused_act = 0, n_elided_cont = 0, n_fused_add = 0;   // launches saved by the fusions of mi355_issue_nodes
 };
 constexpr int MI355_MAX_CPY_DESTS = 4096;
 
@@ -269,8 +269,8 @@ static void mi355_backend_free(ggml_backend_t backend) {
     if (ctx->workspace) mi355q_free(ctx->workspace);
     if (getenv("MI355_GRAPH_STATS")) {
         fprintf(stderr, "MI355 graph_compute calls: %ld eager, %ld captured, %ld replayed\n", ctx->n_eager, ctx->n_captured, ctx->n_replayed);
-        fprintf(stderr, "MI355 fusions (launches saved while issuing nodes): %ld norm*weight, %ld joined matmuls, %ld act*mul, %ld elided CONT\n",
-                ctx->n_fused_norm, ctx->n_fused_mats, ctx->n_fused_act, ctx->n_elided_cont);
+        fprintf(stderr, "MI355 fusions (launches saved while issuing nodes): %ld norm*weight, %ld joined matmuls, %ld act*mul, %ld elided CONT, %ld add+norm\n",
+                ctx->n_fused_norm, ctx->n_fused_mats, ctx->n_fused_act, ctx->n_elided_cont, ctx->n_fused_add);
     }
     if (ctx->graph) mi355q_graph_destroy(ctx->graph);
     if (ctx->dest_table) mi355q_free(ctx->dest_table);
@@ -551,7 +551,31 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
             }
             mi355_glue_op(ctx, node);
         } break;
-        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
+        case GGML_OP_ADD: {
+            // residual ADD -> RMS_NORM -> MUL(weight): one kernel that also stores the sum (it is the next residual's operand)
+            const int j = fz ? fz->next_compute(i) : -1;
+            const int k = j >= 0 && cgraph->nodes[j]->op == GGML_OP_RMS_NORM && cgraph->nodes[j]->src[0] == node ? fz->next_compute(j) : -1;
+            if (k >= 0 && cgraph->nodes[k]->op == GGML_OP_MUL && node->type == GGML_TYPE_F32 && ggml_is_contiguous(node) &&
+                ggml_are_same_shape(node->src[0], node) && ggml_are_same_shape(node->src[1], node) && node->src[0]->type == GGML_TYPE_F32 &&
+                node->src[1]->type == GGML_TYPE_F32 && ggml_is_contiguous(node->src[0]) && ggml_is_contiguous(node->src[1])) {
+                struct ggml_tensor * norm = cgraph->nodes[j], * mul = cgraph->nodes[k];
+                const struct ggml_tensor * w = mul->src[0] == norm ? mul->src[1] : (mul->src[1] == norm ? mul->src[0] : nullptr);
+                // the MUL output is written at the ADD's position: it may coincide exactly with an operand of the ADD (the kernel allows
+                // that) but must not partially overlap one, nor touch the stored sum
+                auto exact_or_disjoint = [&](const struct ggml_tensor * t) { return t->data == mul->data || !mi355_overlap(t, mul); };
+                if (w && w != norm && fz->single_use(norm) && w->type == GGML_TYPE_F32 && ggml_is_contiguous(w) && w->ne[0] == node->ne[0] &&
+                    ggml_nelements(w) == w->ne[0] && ggml_are_same_shape(mul, node) && ggml_is_contiguous(mul) && fz->ready_before(w, i) &&
+                    exact_or_disjoint(node->src[0]) && exact_or_disjoint(node->src[1]) && !mi355_overlap(node, mul)) {
+                    float eps; memcpy(&eps, norm->op_params, sizeof(float));
+                    const mi355q_tensor a = mi355_td(node->src[0]), b = mi355_td(node->src[1]), sum = mi355_td(node), d = mi355_td(mul);
+                    MQ_CHECK(mi355q_op_add_rms_norm_mul(&a, &b, &sum, (const float *) w->data, &d, eps, ctx->stream));
+                    fz->done[(size_t) j] = 1; fz->done[(size_t) k] = 1; ++ctx->n_fused_add;
+                    break;
+                }
+            }
+            mi355_glue_op(ctx, node);
+        } break;
+        case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
         case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
             mi355_glue_op(ctx, node); break;
         default:

@@ -117,9 +117,11 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_mul(const TensorD a, const
     // rows) whatever intrinsics spell it, so each step is done in f64 and rounded to f32
     const float root  = (float) sqrt((double) __fadd_rn(mean, eps));
     const float scale = (float) (1.0 / (double) root);
+    // second pass: with a stored sum it is re-read from there (each thread reads back its own stores), so a and b are not touched after
+    // the barrier -- dst may then alias a or b exactly (same base and strides: row r of dst is row r of the operand, owned by this workgroup)
 #pragma unroll 4
     for (int64_t i = tid; i < n; i += 256) {
-        const float v = has_b ? __fadd_rn(x[i], xb[i]) : x[i];
+        const float v = has_sum ? xs[i] : (has_b ? __fadd_rn(x[i], xb[i]) : x[i]);
         const float t = __fmul_rn(v, scale);
         y[i] = w ? __fmul_rn(t, w[i]) : t;
     }

@@ -124,3 +124,25 @@ def test_mul_mat_f_attention_shapes(G, torch):
     # f32 src0
     y = G.op_mul_mat_f(dev(torch, v), dev(torch, p)).cpu().numpy()
     assert np.abs(y - glue.mul_mat_f(v, p, False)).max() <= 2e-5 * np.abs(y).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# fused forms: bit-identical to the chain of separate ops they replace
+# ------------------------------------------------------------------------------------------------
+def test_fused_norm_and_activation_equal_separate_ops(G, torch):
+    rng = np.random.default_rng(11)
+    for rows, n in ((1, 4096), (5, 4096), (3, 14336), (2, 100)):
+        a = dev(torch, (rng.standard_normal((rows, n)) * 3).astype(np.float32))
+        b = dev(torch, rng.standard_normal((rows, n)).astype(np.float32))
+        w = dev(torch, rng.uniform(0.5, 1.5, (n,)).astype(np.float32))
+        # rms_norm * weight
+        sep = G.op_bin_bcast(G.OP_MUL, G.op_rms_norm(a, 1e-5), w)
+        assert torch.equal(G.op_add_rms_norm_mul(a, 1e-5, weight=w), sep)
+        assert torch.equal(G.op_add_rms_norm_mul(a, 1e-5), G.op_rms_norm(a, 1e-5))
+        # (a + b) stored, then rms_norm * weight
+        s_sep = G.op_bin_bcast(G.OP_ADD, a, b)
+        y_sep = G.op_bin_bcast(G.OP_MUL, G.op_rms_norm(s_sep, 1e-5), w)
+        y, s = G.op_add_rms_norm_mul(a, 1e-5, b=b, weight=w, want_sum=True)
+        assert torch.equal(s, s_sep) and torch.equal(y, y_sep)
+        # silu(a) * b
+        assert torch.equal(G.op_unary_mul(G.UNARY_SILU, a, b), G.op_bin_bcast(G.OP_MUL, G.op_unary(G.UNARY_SILU, a), b))

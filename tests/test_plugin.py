@@ -159,10 +159,10 @@ def test_fused_nodes_bit_identical_to_separate_nodes(n_tokens):
         r = subprocess.run([str(exe), str(n_tokens), "MI355_0", "small", "12"], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "LAYER PARITY OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
         digests.append(re.search(r"device output digest ([0-9a-f]{16})", r.stdout).group(1))
-        m = re.search(r"fusions .*: (\d+) norm\*weight, (\d+) joined matmuls, (\d+) act\*mul, (\d+) elided CONT", r.stderr)
+        m = re.search(r"fusions .*: (\d+) norm\*weight, (\d+) joined matmuls, (\d+) act\*mul, (\d+) elided CONT, (\d+) add\+norm", r.stderr)
         assert m, r.stderr[-2000:]
         saved.append(tuple(map(int, m.groups())))
-    print("launches saved (norm*weight, joined matmuls, act*mul, elided CONT):", saved[0])
+    print("launches saved (norm*weight, joined matmuls, act*mul, elided CONT, add+norm):", saved[0])
     assert digests[0] == digests[1], digests
-    assert saved[1] == (0, 0, 0, 0)
-    assert saved[0][0] > 0 and saved[0][1] > 0 and saved[0][2] > 0
+    assert saved[1] == (0, 0, 0, 0, 0)
+    assert saved[0][0] + saved[0][4] > 0 and saved[0][1] > 0 and saved[0][2] > 0
