@@ -367,8 +367,10 @@ def main():
             flop = 2.0 * Npp * sum(w.M * w.K for grp in stage.groups for w in grp[0])
             out["pp512"] = {"value": round(Npp / secs, 1), "unit": "tok/s", "ms": round(1e3 * secs, 3), "TFLOPs": round(flop / secs / 1e12, 1),
                             "roofline": {"bound": "mfma", "achieved": round(flop / secs / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                                         "frac": round(flop / secs / 1e12 / 2500.0, 4), "kernel": "k_mmq_bf16 (bf16 MFMA 16x16x32, f32 accumulate)"},
-                            "note": "all quantized matmuls of the model at N = 512, one launch each; operands bf16 (weights dequantized in f32 first)"}
+                                         "frac": round(flop / secs / 1e12 / 2500.0, 4),
+                                         "kernel": "k_mmq_i8_q4k (Q4_K: int8 MFMA 16x16x64 on Q8_K activations, exact integer block sums) + k_mmq_bf16 (other types: bf16 MFMA 16x16x32)",
+                                         "peak_note": "dense bf16 MFMA peak; the int8 instructions of the Q4_K kernel have twice that"},
+                            "note": "all quantized matmuls of the model at N = 512, one launch each (+ one activation-preparation launch)"}
             del xs_pp, ys_pp
         if not a.no_cpu_baseline and world == 1 and a.model == "llama3-8b":      # (the headline config; the reference chain has no MUL_MAT_ID leg)
             try:
