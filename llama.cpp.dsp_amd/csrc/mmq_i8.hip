@@ -255,9 +255,10 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
     uint8_t * xs = xq + (size_t) nb * n_pad * I8Q_REC;
     float   * xd = (float *) (xs + (size_t) nb * n_pad * I8Q_XS);
     hipLaunchKernelGGL(k_mmq_i8_prep, dim3((unsigned) nb, (unsigned) (n_pad / 4)), dim3(256), 0, stream, x, x_stride, xq, xs, xd, (int) n, (int) n_pad, nb);
-    // 128 rows x 128 tokens per workgroup when that still gives every CU a workgroup; otherwise 64-token tiles (twice the workgroups)
+    // 128 rows x 128 tokens per workgroup (the dequantization is shared by most tokens) when that still gives a CU 1.5 workgroups;
+    // otherwise 64 x 64 (four times the workgroups, 3-4 per CU): measured at N = 512, 4096 x 4096: 47 -> 42 us, 4096 x 14336: 147 -> 128 us
     const int64_t rb = (m + 127) / 128;
-    const bool wide = rb * (n_pad / 128) >= n_cu;
+    const bool wide = 2 * rb * (n_pad / 128) >= 3 * (int64_t) n_cu;
 #define MI355Q_I8_LAUNCH(RT, TT, STAMPS) {                                                                                                   \
         constexpr int bn = 16 * TT;                                                                                                \
         const size_t lds_bytes = 2 * (size_t) (bn * (I8Q_REC + I8Q_XS + 4)); \
@@ -272,8 +273,12 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
                            (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, y, y_stride, (int) m, (int) n, (int) n_pad, nb, \
                            n_tok_tiles, total, per_xcd); }
     static const bool stamps = getenv("MI355Q_I8_STAMPS") != nullptr;       // dev: phase times of workgroup 0 into y[0][0..3] (tools/pp_shape.py)
-    if (wide) { if (stamps) MI355Q_I8_LAUNCH(2, 8, true) else MI355Q_I8_LAUNCH(2, 8, false) }
-    else MI355Q_I8_LAUNCH(2, 4, false)
+    static const int force = getenv("MI355Q_I8_CFG") ? atoi(getenv("MI355Q_I8_CFG")) : 0;      // dev: 28 / 24 / 18 / 14 = RT, TT
+    const int cfg = force ? force : (wide ? 28 : 14);
+    if (cfg == 28) { if (stamps) MI355Q_I8_LAUNCH(2, 8, true) else MI355Q_I8_LAUNCH(2, 8, false) }
+    else if (cfg == 24) MI355Q_I8_LAUNCH(2, 4, false)
+    else if (cfg == 18) MI355Q_I8_LAUNCH(1, 8, false)
+    else MI355Q_I8_LAUNCH(1, 4, false)
 #undef MI355Q_I8_LAUNCH
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
 }
