@@ -127,6 +127,61 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_mul(const TensorD a, const
     }
 }
 
+// The same kernel for rows of at most 1024*NV4 elements with 16-byte aligned operands: every thread keeps its NV4 float4 pieces of the
+// row in registers (one read of the operands, 16-byte accesses).  Same f32 operations; only the order of the f64 partial sums differs.
+template <int NV4>
+__global__ void __launch_bounds__(256) k_add_rms_norm_mul_vec(const TensorD a, const TensorD b, int has_b, const TensorD sum, int has_sum,
+                                                              const float * __restrict__ w, const TensorD d, float eps) {
+    __shared__ double part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % a.ne[1], r2 = row / a.ne[1], i2 = r2 % a.ne[2], i3 = r2 / a.ne[2];
+    const float4 * x = (const float4 *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    const float4 * xb = has_b ? (const float4 *) (b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3]) : nullptr;
+    float4 * xs = has_sum ? (float4 *) (sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]) : nullptr;
+    float4 * y = (float4 *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int64_t n4 = a.ne[0] / 4;
+    float4 v[NV4];
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) {
+        const int64_t i = tid + 256 * u;
+        v[u] = i < n4 ? x[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (has_b) {
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) {
+            const int64_t i = tid + 256 * u;
+            if (i < n4) { const float4 t = xb[i]; v[u].x = __fadd_rn(v[u].x, t.x); v[u].y = __fadd_rn(v[u].y, t.y); v[u].z = __fadd_rn(v[u].z, t.z); v[u].w = __fadd_rn(v[u].w, t.w); }
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) {
+        const int64_t i = tid + 256 * u;
+        if (i < n4) {
+            if (has_sum) xs[i] = v[u];
+            s += (double) __fmul_rn(v[u].x, v[u].x); s += (double) __fmul_rn(v[u].y, v[u].y);
+            s += (double) __fmul_rn(v[u].z, v[u].z); s += (double) __fmul_rn(v[u].w, v[u].w);
+        }
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    s = (part[0] + part[1]) + (part[2] + part[3]);
+    const float mean  = (float) (s / (double) a.ne[0]);
+    const float root  = (float) sqrt((double) __fadd_rn(mean, eps));      // both roundings of the CPU (see k_add_rms_norm_mul)
+    const float scale = (float) (1.0 / (double) root);
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) {
+        const int64_t i = tid + 256 * u;
+        if (i < n4) {
+            float4 t = make_float4(__fmul_rn(v[u].x, scale), __fmul_rn(v[u].y, scale), __fmul_rn(v[u].z, scale), __fmul_rn(v[u].w, scale));
+            if (w) { const float4 ww = ((const float4 *) w)[i]; t.x = __fmul_rn(t.x, ww.x); t.y = __fmul_rn(t.y, ww.y); t.z = __fmul_rn(t.z, ww.z); t.w = __fmul_rn(t.w, ww.w); }
+            y[i] = t;
+        }
+    }
+}
+
 // ---- fused UNARY * other (SiLU(gate) * up): contiguous f32 tensors of one shape ---------------------------------
 template <int OP>
 __global__ void __launch_bounds__(256) k_unary_mul(const float * __restrict__ a, const float * __restrict__ b, float * __restrict__ d, int64_t n) {
@@ -187,6 +242,45 @@ __global__ void __launch_bounds__(256) k_soft_max(const TensorD a, const TensorD
     for (int64_t i = lane; i < nc; i += 64) dp[i] = __fmul_rn(dp[i], inv);
 }
 
+// The same row softmax with the row held in registers (rows of at most 64*NV elements: every decode-sized attention window): one read
+// of the scores and the mask instead of three dependent passes through memory.  Same expressions, same lane-strided order of the f64
+// sum as k_soft_max: bit-identical to it.
+template <int NV>
+__global__ void __launch_bounds__(256) k_soft_max_reg(const TensorD a, const TensorD m, const TensorD d, float scale, float max_bias,
+                                                      float m0, float m1, uint32_t n_head_log2, int64_t nrows, int has_mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t nc = a.ne[0];
+    const float * sp = (const float *) (a.data + row * a.nb[1]);
+    float * dp = (float *) (d.data + row * d.nb[1]);
+    const uint32_t h = (uint32_t) ((row / a.ne[1]) % a.ne[2]);
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const char * mp = has_mask ? m.data + (row % a.ne[1]) * nc * (m.type == 0 ? 4 : 2) : nullptr;
+    float v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int64_t i = lane + 64 * u;
+        float x = -INFINITY;
+        if (i < nc) {
+            x = __fmul_rn(sp[i], scale);
+            if (mp) x = __fadd_rn(x, __fmul_rn(slope, m.type == 0 ? ((const float *) mp)[i] : __half2float(((const __half *) mp)[i])));
+        }
+        v[u] = x; mx = fmaxf(mx, x);
+    }
+    mx = wave_max_f32(mx);
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if (lane + 64 * u < nc) { const float e = expf(__fsub_rn(v[u], mx)); v[u] = e; sum += (double) e; }
+    }
+    sum = wave_sum_f64(sum);
+    const float inv = (float) (1.0 / sum);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) if (lane + 64 * u < nc) dp[lane + 64 * u] = __fmul_rn(v[u], inv);
+}
+
 // ---- ROPE (normal and neox modes, YaRN scaling, optional frequency factors): one thread per rotated pair ------------
 //   ggml-cpu/ops.cpp:4990-5028 (rope_yarn, ggml_rope_cache_init), :5088-5270 (ggml_compute_forward_rope_f32)
 struct RopeP { int n_dims, neox; float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1; };
@@ -227,21 +321,40 @@ __global__ void __launch_bounds__(256) k_rope(const TensorD a, const int32_t * p
 // ---- MUL_MAT with an f16 / f32 src0 (attention KQ and KQV): one wave per output element ---------------------------
 //   dst[m, n, i12, i13] = sum_k a[k, m, i12/r2, i13/r3] * b[k, n, i12, i13]   (ggml-cpu.c:1266-1458; an f16 src0 makes the CPU
 //   round src1 to f16 first, vec_dot_type = F16 -- reproduced; the products are accumulated in f32)
-__global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const TensorD b, const TensorD d, int64_t n_out) {
+constexpr int MMF_ROWS = 8;        // src0 rows per wave: their loads are in flight together (one row per wave is a memory round trip per 4 bytes of output)
+__global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const TensorD b, const TensorD d, int64_t n_groups, int64_t groups_per_col) {
     const int lane = threadIdx.x & 63;
     const int64_t o = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (o >= n_out) return;
-    const int64_t m = o % d.ne[0], r = o / d.ne[0], n = r % d.ne[1], r2 = r / d.ne[1], i12 = r2 % d.ne[2], i13 = r2 / d.ne[2];
+    if (o >= n_groups) return;
+    const int64_t mg = o % groups_per_col, r = o / groups_per_col, n = r % d.ne[1], r2 = r / d.ne[1], i12 = r2 % d.ne[2], i13 = r2 / d.ne[2];
     const int64_t i02 = i12 / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
-    const char * ap = a.data + m * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3];
+    const int64_t m0 = mg * MMF_ROWS, M = d.ne[0];
+    const char * abase = a.data + i02 * a.nb[2] + i03 * a.nb[3];
     const float * bp = (const float *) (b.data + n * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3]);
     const int64_t K = a.ne[0];
-    float s = 0.0f;
-    if (a.type == 1) for (int64_t k = lane; k < K; k += 64) s += __half2float(((const __half *) ap)[k]) * __half2float(__float2half_rn(bp[k]));
-    else             for (int64_t k = lane; k < K; k += 64) s += ((const float *) ap)[k] * bp[k];
+    float s[MMF_ROWS];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) *(float *) (d.data + m * d.nb[0] + n * d.nb[1] + i12 * d.nb[2] + i13 * d.nb[3]) = s;
+    for (int q = 0; q < MMF_ROWS; ++q) s[q] = 0.0f;
+    // per output the same lane-strided products and additions, in the same order, as one row per wave would make
+    if (a.type == 1) {
+        for (int64_t k = lane; k < K; k += 64) {
+            const float bv = __half2float(__float2half_rn(bp[k]));                       // the CPU converts src1 to src0's vec_dot_type (f16) first
+#pragma unroll
+            for (int q = 0; q < MMF_ROWS; ++q) s[q] += __half2float(((const __half *) (abase + (m0 + q < M ? m0 + q : m0) * a.nb[1]))[k]) * bv;
+        }
+    } else {
+        for (int64_t k = lane; k < K; k += 64) {
+            const float bv = bp[k];
+#pragma unroll
+            for (int q = 0; q < MMF_ROWS; ++q) s[q] += ((const float *) (abase + (m0 + q < M ? m0 + q : m0) * a.nb[1]))[k] * bv;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MMF_ROWS; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_xor(s[q], off, 64);
+        if (lane == 0 && m0 + q < M) *(float *) (d.data + (m0 + q) * d.nb[0] + n * d.nb[1] + i12 * d.nb[2] + i13 * d.nb[3]) = s[q];
+    }
 }
 
 // ---- GET_ROWS (f32 / f16 rows -> f32): dst[:, i10, i11, i12] = src0[:, ids[i10, i11, i12], i11, i12]   ops.cpp:4272-4311 -------
@@ -310,12 +423,23 @@ int mi355q_op_unary(int uop, const mi355q_tensor * a, const mi355q_tensor * dst,
     OPS_LAUNCHED();
 }
 
+static void launch_rms(const mi355q_tensor * a, const mi355q_tensor * b, const mi355q_tensor * sum, const float * weight, const mi355q_tensor * dst,
+                       float eps, int64_t nrows, hipStream_t st) {
+    auto al16 = [](const mi355q_tensor * t) { return !t || ((((uintptr_t) t->data) | (uintptr_t) t->nb[1] | (uintptr_t) t->nb[2] | (uintptr_t) t->nb[3]) & 15) == 0; };
+    const bool vec = a->ne[0] % 4 == 0 && al16(a) && al16(b) && al16(sum) && al16(dst) && (((uintptr_t) weight) & 15) == 0;
+    const dim3 grid((unsigned) nrows), block(256);
+    const TensorD ta = to_d(a), tb = b ? to_d(b) : to_d(a), ts = sum ? to_d(sum) : to_d(a), td = to_d(dst);
+    if (vec && a->ne[0] <= 4096)       hipLaunchKernelGGL(k_add_rms_norm_mul_vec<4>,  grid, block, 0, st, ta, tb, b ? 1 : 0, ts, sum ? 1 : 0, weight, td, eps);
+    else if (vec && a->ne[0] <= 16384) hipLaunchKernelGGL(k_add_rms_norm_mul_vec<16>, grid, block, 0, st, ta, tb, b ? 1 : 0, ts, sum ? 1 : 0, weight, td, eps);
+    else                               hipLaunchKernelGGL(k_add_rms_norm_mul,        grid, block, 0, st, ta, tb, b ? 1 : 0, ts, sum ? 1 : 0, weight, td, eps);
+}
+
 int mi355q_op_rms_norm(const mi355q_tensor * a, const mi355q_tensor * dst, float eps, void * stream) {
     if (!a || !dst || !same_shape(a, dst) || a->type != 0 || dst->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_rms_norm: f32 tensors of one shape");
     if (a->nb[0] != 4 || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_rms_norm: rows must be contiguous");
     const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
     if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_add_rms_norm_mul, dim3((unsigned) nrows), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(a), 0, to_d(a), 0, (const float *) nullptr, to_d(dst), eps);
+    launch_rms(a, nullptr, nullptr, nullptr, dst, eps, nrows, (hipStream_t) stream);
     OPS_LAUNCHED();
 }
 
@@ -330,8 +454,7 @@ int mi355q_op_add_rms_norm_mul(const mi355q_tensor * a, const mi355q_tensor * b,
     if (a->nb[0] != 4 || dst->nb[0] != 4 || (b && b->nb[0] != 4) || (sum && sum->nb[0] != 4)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_add_rms_norm_mul: rows must be contiguous");
     const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
     if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_add_rms_norm_mul, dim3((unsigned) nrows), dim3(256), 0, (hipStream_t) stream, to_d(a), b ? to_d(b) : to_d(a), b ? 1 : 0,
-                       sum ? to_d(sum) : to_d(a), sum ? 1 : 0, weight, to_d(dst), eps);
+    launch_rms(a, b, sum, weight, dst, eps, nrows, (hipStream_t) stream);
     OPS_LAUNCHED();
 }
 
@@ -410,8 +533,10 @@ int mi355q_op_soft_max(const mi355q_tensor * a, const mi355q_tensor * mask, cons
     uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= n_head) n_head_log2 *= 2;
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
     TensorD md = mask ? to_d(mask) : to_d(a);
-    hipLaunchKernelGGL(k_soft_max, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias,
-                       m0, m1, n_head_log2, nrows, mask ? 1 : 0);
+    const dim3 grid((unsigned) ((nrows + 3) / 4)), block(256);
+    if (a->ne[0] <= 512)       hipLaunchKernelGGL(k_soft_max_reg<8>,  grid, block, 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias, m0, m1, n_head_log2, nrows, mask ? 1 : 0);
+    else if (a->ne[0] <= 2048) hipLaunchKernelGGL(k_soft_max_reg<32>, grid, block, 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias, m0, m1, n_head_log2, nrows, mask ? 1 : 0);
+    else                       hipLaunchKernelGGL(k_soft_max,         grid, block, 0, (hipStream_t) stream, to_d(a), md, to_d(dst), scale, max_bias, m0, m1, n_head_log2, nrows, mask ? 1 : 0);
     OPS_LAUNCHED();
 }
 
@@ -462,8 +587,9 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
     if (a->nb[0] != (a->type == 0 ? 4 : 2) || b->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: the k dimension must be contiguous in both operands");
     const int64_t n_out = nelements(dst);
     if (n_out == 0) return MI355Q_OK;
-    if ((n_out + 3) / 4 > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: too many outputs");
-    hipLaunchKernelGGL(k_mul_mat_f, dim3((unsigned) ((n_out + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n_out);
+    const int64_t groups_per_col = (dst->ne[0] + MMF_ROWS - 1) / MMF_ROWS, n_groups = groups_per_col * dst->ne[1] * dst->ne[2] * dst->ne[3];
+    if ((n_groups + 3) / 4 > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: too many outputs");
+    hipLaunchKernelGGL(k_mul_mat_f, dim3((unsigned) ((n_groups + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n_groups, groups_per_col);
     OPS_LAUNCHED();
 }
 
