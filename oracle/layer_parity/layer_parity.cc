@@ -74,8 +74,10 @@ static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens
     ggml_tensor * Q = ggml_mul_mat(c, M.wq, cur), * K = ggml_mul_mat(c, M.wk, cur), * V = ggml_mul_mat(c, M.wv, cur);
     Q = ggml_rope_ext(c, ggml_reshape_3d(c, Q, d.hd, d.n_head, n_tokens), S.pos, nullptr, d.hd, 0, 8192, 500000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
     K = ggml_rope_ext(c, ggml_reshape_3d(c, K, d.hd, d.n_head_kv, n_tokens), S.pos, nullptr, d.hd, 0, 8192, 500000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
-    // --- store k, v in the cache (llama_kv_cache_unified cpy_k / cpy_v; V transposed when flash attention is off)
+    // --- build_attn (src/llama-graph.cpp:1384-1388): q, k, v enter the graph together, before the cache stores
     S.gf = ggml_new_graph(c);
+    ggml_build_forward_expand(S.gf, Q); ggml_build_forward_expand(S.gf, K); ggml_build_forward_expand(S.gf, V);
+    // --- store k, v in the cache (llama_kv_cache_unified cpy_k / cpy_v; V transposed when flash attention is off)
     ggml_tensor * k_view = ggml_view_1d(c, M.kc, (int64_t) n_tokens * n_embd_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv) * n_past);
     ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_reshape_2d(c, K, n_embd_kv, n_tokens), k_view));
     ggml_tensor * v_view = ggml_view_2d(c, M.vc, n_tokens, n_embd_kv, d.n_ctx * ggml_element_size(M.vc), n_past * ggml_element_size(M.vc));
