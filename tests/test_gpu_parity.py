@@ -246,7 +246,9 @@ def test_kquant_bitexact_on_exact_inputs(G, torch, orc, t):
 # MFMA (prefill) tier: N > 8
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("t", MMQ_TYPES, ids=ids_t)
-@pytest.mark.parametrize("shape", [(128, 9, 2048), (256, 64, 4096), (200, 130, 2048), (1024, 512, 4096), (96, 33, 14336)], ids=str)
+@pytest.mark.parametrize("shape", [(128, 9, 2048), (256, 64, 4096), (200, 130, 2048), (1024, 512, 4096), (96, 33, 14336),
+                                   (12288, 512, 2048)],       # (the last one is large enough for the 128 x 128-tile kernels)
+                         ids=str)
 def test_mfma_tier(G, torch, orc, t, shape):
     M, N, K = shape
     rng = np.random.default_rng(M + N + K + t)
