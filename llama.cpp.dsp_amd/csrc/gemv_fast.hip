@@ -234,11 +234,14 @@ int gemv_fast_max_cols(int type, int64_t k) {
 template <int FAM, int WT, int NCOLS, int D, bool EVEN, bool MULTI>
 static int launch_one_m(const GemvArgs & a, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     auto kern = k_gemv_fast<FAM, WT, NCOLS, D, EVEN, MULTI>;
-    static size_t lds_enabled = 48 * 1024;                 // per kernel instantiation
-    if (lds_bytes > lds_enabled) {
-        if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MI355Q_ERR_HIP;
-        lds_enabled = 160 * 1024;
+    static bool lds_enabled[64] = {};                      // per kernel instantiation AND per device (the plugin drives every GPU from one process)
+    if (lds_bytes > 48 * 1024) {
+        int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
+        if (!lds_enabled[dev]) {
+            if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return MI355Q_ERR_HIP;
+            lds_enabled[dev] = true;
+        }
     }
     hipLaunchKernelGGL(kern, grid, dim3(GEMV_THREADS), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;

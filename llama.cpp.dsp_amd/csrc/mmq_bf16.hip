@@ -324,11 +324,12 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     const dim3 grid((unsigned) ((m + bm - 1) / bm), (unsigned) ((n + bn - 1) / bn));
 #define MI355Q_MMQ_LAUNCH(T, BM, BN) {                                                                                             \
         constexpr size_t lds_bytes = (size_t) (BM + BN) * MMQ_LDS_STRIDE;          /* 68 / 51 / 34 KiB */                           \
-        static bool attr_set = false;                                                                                              \
-        if (!attr_set) {                                                                                                           \
+        static bool attr_set[64] = {};          /* the attribute is per device: the plugin drives every visible GPU from one process */ \
+        int dev_ = 0; (void) hipGetDevice(&dev_); dev_ = dev_ >= 0 && dev_ < 64 ? dev_ : 0;                                          \
+        if (!attr_set[dev_]) {                                                                                                     \
             if (hipFuncSetAttribute((const void *) k_mmq_bf16<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess) \
                 return MI355Q_ERR_HIP;                                                                                             \
-            attr_set = true;                                                                                                       \
+            attr_set[dev_] = true;                                                                                                 \
         }                                                                                                                          \
         hipLaunchKernelGGL((k_mmq_bf16<T, BM, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,     \
                            (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k); }

@@ -51,17 +51,21 @@ k_mmq_i8_prep(const float * __restrict__ x, int64_t x_stride, uint8_t * __restri
         const float4 v = *(const float4 *) ((const char *) x + (int64_t) tok * x_stride + 4 * (256 * (int64_t) b + 4 * lane));
         q8k_wave(v, q, d, bsum);
     }
-    const int P = lane >> 2, s = 2 * (P >> 3) + ((P >> 1) & 1), kq = 2 * ((P >> 2) & 1) + (P & 1);
-    *(uint32_t *) (rec + 64 * s + 16 * kq + 4 * (lane & 3)) = q;
+    // Record byte 4*L comes from source dword D(L): the record is [step s][lane quarter kq][16 B] and holds source piece P = 8a+4b+2c+d at
+    // s = 2a+c, kq = 2b+d.  The quants are exchanged between lanes (one ds_bpermute) so that the wave writes its 256 bytes as ONE contiguous
+    // store -- written from the natural order the record is 16 scattered 16-byte segments and the kernel runs at a third of the speed.
+    const int s = lane >> 4, kq = (lane >> 2) & 3, P = 8 * (s >> 1) + 4 * (kq >> 1) + 2 * (s & 1) + (kq & 1);
+    const uint32_t qp = (uint32_t) __shfl((int) q, 4 * P + (lane & 3), 64);
+    *(uint32_t *) (rec + 4 * lane) = qp;
     if (lane < 4) *(uint32_t *) (rec + 256 + 4 * lane) = 0u;
     if (lane == 0) xd[(int64_t) b * n_pad + tok] = d;
-    const int bs32 = bsum + __shfl_xor(bsum, 4);                           // sum of the 32-group (lanes 8g..8g+7)
-    if ((lane & 7) == 0) {
-        const int g = lane >> 3, half = (g >> 1) & 1, pos = (g & 1) + 2 * (g >> 2);
-        const int lo = bs32 & 63, hi = bs32 >> 6;                          // bs32 = 64*hi + lo (arithmetic shift), |hi| <= 64
-        *(uint16_t *) (srec + 2 * (8 * half + pos))     = (uint16_t) (__float_as_uint((float) lo) >> 16);    // small integers: exact in bf16
-        *(uint16_t *) (srec + 2 * (8 * half + 4 + pos)) = (uint16_t) (__float_as_uint((float) hi) >> 16);
-    }
+    // group sums: the 32-group g lives in lanes 8g..8g+7; lanes 0..7 each assemble one dword (two bf16) of the 32-byte record
+    const int bs32 = bsum + __shfl_xor(bsum, 4);
+    const int k8 = lane & 7;
+    const int g0 = (k8 & 4 ? 2 : 0) + (k8 & 1 ? 4 : 0), want_hi = (k8 >> 1) & 1;      // dwords: (lo0 lo1)(lo4 lo5)(hi0 hi1)(hi4 hi5) | (lo2 lo3)(lo6 lo7)(hi2 hi3)(hi6 hi7)
+    const int sa = __shfl(bs32, 8 * g0, 64), sb = __shfl(bs32, 8 * (g0 + 1), 64);
+    const int va = want_hi ? sa >> 6 : sa & 63, vb = want_hi ? sb >> 6 : sb & 63;       // bs32 = 64*hi + lo (arithmetic shift), 0 <= lo < 64, |hi| <= 64
+    if (lane < 8) *(uint32_t *) (srec + 4 * lane) = (__float_as_uint((float) va) >> 16) | (__float_as_uint((float) vb) & 0xFFFF0000u);   // small integers: exact in bf16
 }
 
 __device__ __forceinline__ uint32_t i8q_mul_bytes(uint32_t nib, uint32_t mul16x2) {     // 4 bytes (each <= 15) times a multiplier <= 7: one v_pk_mul_lo_u16
@@ -262,11 +266,12 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
 #define MI355Q_I8_LAUNCH(RT, TT, STAMPS) {                                                                                                   \
         constexpr int bn = 16 * TT;                                                                                                \
         const size_t lds_bytes = 2 * (size_t) (bn * (I8Q_REC + I8Q_XS + 4)); \
-        static bool attr_set = false;                                                                                              \
-        if (!attr_set) {                                                                                                           \
+        static bool attr_set[64] = {};          /* the attribute is per device: the plugin drives every visible GPU from one process */ \
+        int dev_ = 0; (void) hipGetDevice(&dev_); dev_ = dev_ >= 0 && dev_ < 64 ? dev_ : 0;                                          \
+        if (!attr_set[dev_]) {                                                                                                     \
             if (hipFuncSetAttribute((const void *) k_mmq_i8_q4k<RT, TT, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes) != hipSuccess) \
                 return MI355Q_ERR_HIP;                                                                                             \
-            attr_set = true;                                                                                                       \
+            attr_set[dev_] = true;                                                                                                 \
         }                                                                                                                          \
         const int n_tok_tiles = (int) (n_pad / bn), total = (int) (((m + 64 * RT - 1) / (64 * RT)) * n_tok_tiles), per_xcd = (total + 7) / 8; \
         hipLaunchKernelGGL((k_mmq_i8_q4k<RT, TT, STAMPS>), dim3((unsigned) (8 * per_xcd)), dim3(256), lds_bytes, stream, (const uint8_t *) w, w_stride, \

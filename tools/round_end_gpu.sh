@@ -10,6 +10,7 @@ cut -c1-300 gpurun_out/bench_r1.json
 rm -rf gpurun_out/prof_kt gpurun_out/prof_pmc
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1 || echo "rocprofv3 kernel-trace pass exited with $? (its CSVs are written before the profiler's exit-time crash with cooperative launches)"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_pmc -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/prof_pmc.log 2>&1 || echo "rocprofv3 pmc pass exited with $?"
+cp gpurun_out/bench_r1.json profiles/round1_bench.json
 python tools/summarize_profile.py round1 gpurun_out/prof_kt gpurun_out/prof_pmc
 # one resident decoder layer through the plugin: timing with / without launch graphs and fusions, and its kernel timeline
 export GGML_BACKEND_PATH=$GRAFT_REPO_ROOT/llama.cpp.dsp_amd/lib/libggml-mi355.so
