@@ -355,16 +355,30 @@ def main():
                            "measured_hbm_read_peak_GBps": measured_hbm_read_GBps(torch, device),   # this box, plain streaming read (guide: ~6.3 TB/s)
                            "all_kernels": all_kernels}
         # ---- pp512: the same weights at N = 512 on the MFMA tier (second half of the north-star metric) ----
-        if not a.no_pp and world == 1 and not stage.has_moe:
+        if not a.no_pp and world == 1:
             Npp = 512
             xs_pp = {k: torch.randn((Npp, k), dtype=torch.float32, device=device) for k in {w.K for grp in stage.groups for w in grp[0]}}
             ys_pp = {m: torch.empty((Npp, m), dtype=torch.float32, device=device) for m in {w.M for grp in stage.groups for w in grp[0]}}
+            # MoE: every token picks n_used distinct experts at random (a uniform router); MUL_MAT_ID groups the rows by expert
+            ids_pp, xs_moe = {}, {}
+            for grp in stage.groups:
+                if grp[4] is not None:
+                    w = grp[0][0]
+                    n_used = int(grp[4].shape[-1])
+                    if (w.n_expert, n_used) not in ids_pp:
+                        ids_pp[(w.n_expert, n_used)] = torch.stack([torch.randperm(w.n_expert, device=device)[:n_used] for _ in range(Npp)]).to(torch.int32)
+                    if w.K not in xs_moe:
+                        xs_moe[w.K] = torch.randn((Npp, 1, w.K), dtype=torch.float32, device=device)
             def pp():
                 for grp in stage.groups:
-                    for w in grp[0]:
-                        g.mul_mat(w, xs_pp[w.K], out=ys_pp[w.M])
+                    if grp[4] is not None:
+                        w = grp[0][0]
+                        g.mul_mat_id(w, xs_moe[w.K], ids_pp[(w.n_expert, int(grp[4].shape[-1]))])
+                    else:
+                        for w in grp[0]:
+                            g.mul_mat(w, xs_pp[w.K], out=ys_pp[w.M])
             secs = timed(pp, 3)
-            flop = 2.0 * Npp * sum(w.M * w.K for grp in stage.groups for w in grp[0])
+            flop = 2.0 * Npp * sum(w.M * w.K * (int(grp[4].shape[-1]) if grp[4] is not None else 1) for grp in stage.groups for w in grp[0])
             out["pp512"] = {"value": round(Npp / secs, 1), "unit": "tok/s", "ms": round(1e3 * secs, 3), "TFLOPs": round(flop / secs / 1e12, 1),
                             "roofline": {"bound": "mfma", "achieved": round(flop / secs / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                          "frac": round(flop / secs / 1e12 / 2500.0, 4),

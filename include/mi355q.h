@@ -164,7 +164,10 @@ int    mi355q_mul_mat_multi(const mi355q_mat *mats, int n_mats,
  * w: n_expert consecutive matrices of m device rows each (expert stride = expert_stride_bytes);
  * x: f32 [n_tok][x_ne1][k] contiguous rows with strides x_stride1_bytes (slot) and x_stride2_bytes (token);
  * ids: i32 device [n_tok][n_used] with row stride ids_stride_bytes;  y: f32 [n_tok][n_used][m] contiguous.
- * The expert ids are read ON THE DEVICE (no host round trip, cf. ggml-cuda.cu:2008-2011). */
+ * Up to 16 (token, slot) pairs the expert ids are read ON THE DEVICE (no host round trip: decode stays capturable).  From 17 pairs on
+ * (prefill) the rows are grouped by expert on the host -- a stream synchronize, as the reference's CUDA path does (ggml-cuda.cu
+ * ggml_cuda_mul_mat_id) -- gathered, multiplied per expert by the ordinary mul_mat tiers and scattered back; size the workspace
+ * with mi355q_mul_mat_id_workspace. */
 size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1);
 int    mi355q_mul_mat_id(int type, const void *w, int64_t w_stride_bytes, int64_t expert_stride_bytes, int64_t n_expert,
                          const float *x, int64_t x_ne1, int64_t x_stride1_bytes, int64_t x_stride2_bytes,

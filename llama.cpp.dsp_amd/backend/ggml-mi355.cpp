@@ -593,7 +593,10 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
     static const bool env_off = getenv("MI355_NO_GRAPHS") != nullptr;
-    const bool try_graphs = !env_off && !ctx->graphs_disabled && cgraph->n_nodes >= 8;
+    bool try_graphs = !env_off && !ctx->graphs_disabled && cgraph->n_nodes >= 8;
+    // a prefill-sized MUL_MAT_ID groups its rows by expert on the host (a stream synchronize inside): such a graph cannot be captured
+    for (int i = 0; try_graphs && i < cgraph->n_nodes; ++i)
+        if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT_ID && cgraph->nodes[i]->src[2]->ne[0] * cgraph->nodes[i]->src[2]->ne[1] >= 17) try_graphs = false;
 
     // destination pointers of the CPY nodes of THIS call
     int n_cpy = 0;

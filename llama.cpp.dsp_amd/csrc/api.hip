@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace mi355q {
 // kernels (other translation units)
@@ -51,6 +52,30 @@ static int cu_count() {
         have[dev] = true;
     }
     return cached[dev];
+}
+
+static int64_t moe_align256(int64_t v) { return (v + 255) & ~(int64_t) 255; }
+extern "C" size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k);
+
+// ---- grouped MUL_MAT_ID (many (token, slot) pairs): rows gathered by expert, one ordinary matmul per expert, rows scattered back ----
+// xg[i][:] = x[tok(order[i])][slot(order[i]) % x_ne1][:]        (order = pair indices sorted by expert)
+__global__ void __launch_bounds__(256) k_moe_gather(const char * __restrict__ x, int64_t x_stride1, int64_t x_stride2, int n_used, int x_ne1,
+                                                    const int32_t * __restrict__ order, float * __restrict__ xg, int64_t k) {
+    const int p = order[blockIdx.x], t = p / n_used, u = p - t * n_used;
+    const float * src = (const float *) (x + (int64_t) t * x_stride2 + (int64_t) (u % x_ne1) * x_stride1);
+    float * dst = xg + (int64_t) blockIdx.x * k;
+    for (int64_t i = threadIdx.x; i < k; i += 256) dst[i] = src[i];
+}
+// y[order[i]][:] = yg[i][:]
+__global__ void __launch_bounds__(256) k_moe_scatter(const float * __restrict__ yg, const int32_t * __restrict__ order, float * __restrict__ y, int64_t m) {
+    const float * src = yg + (int64_t) blockIdx.x * m;
+    float * dst = y + (int64_t) order[blockIdx.x] * m;
+    for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = src[i];
+}
+constexpr int64_t MOE_GROUPED_MIN_PAIRS = 17;      // below: one GEMV column per pair with the ids read on the device (no host round trip)
+static size_t moe_grouped_workspace(int type, int64_t m, int64_t k, int64_t pairs) {
+    // [order: pairs i32][xg: pairs x k f32][yg: pairs x m f32][scratch of the per-expert matmul, worst case all pairs on one expert]
+    return (size_t) (moe_align256(4 * pairs) + moe_align256(4 * pairs * k) + moe_align256(4 * pairs * m)) + mi355q_mul_mat_workspace(type, m, pairs, k);
 }
 } // namespace mi355q
 
@@ -270,11 +295,12 @@ int mi355q_mul_mat(int type, const void * w, int64_t w_stride, const float * x, 
 
 // ---- MUL_MAT_ID ----
 size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1) {
-    (void) m; (void) n_used;
     const TypeInfo * t = type_info(type);
     if (!t || t->act < 0 || k % t->blck) return 0;
-    if (is_planar(t, k)) return 0;
-    return (size_t) align256(mi355q_row_size(t->act, k) * n_tok * x_ne1);
+    const size_t grouped = n_used * n_tok >= MOE_GROUPED_MIN_PAIRS ? moe_grouped_workspace(type, m, k, n_used * n_tok) : 0;
+    if (is_planar(t, k)) return grouped;
+    const size_t generic = (size_t) align256(mi355q_row_size(t->act, k) * n_tok * x_ne1);
+    return grouped > generic ? grouped : generic;
 }
 
 int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert_stride, int64_t n_expert,
@@ -290,6 +316,39 @@ int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert
     if (pairs == 0 || m == 0) return MI355Q_OK;
     if (pairs > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat_id: more than 65535 (token,slot) pairs per call");
     hipStream_t st = (hipStream_t) stream;
+    if (pairs >= MOE_GROUPED_MIN_PAIRS) {
+        // Prefill-sized batches: the reference's grouped form -- rows are grouped by expert on the HOST (the CPU backend's row
+        // grouping, ggml-cpu.c:1628-1643; the CUDA backend copies the ids to the host the same way, ggml-cuda.cu mul_mat_id), every
+        // expert's rows are gathered into one contiguous block, multiplied by an ordinary mul_mat (GEMV tier up to 8 rows, the matrix-
+        // core tiers above) and scattered back.  One GEMV column per pair would re-stream an expert's weights once per pair.
+        if (!workspace || workspace_bytes < moe_grouped_workspace(type, m, k, pairs)) return fail(MI355Q_ERR_WORKSPACE, "mul_mat_id: workspace too small for the grouped form");
+        std::vector<int32_t> h_ids((size_t) pairs);
+        HIP_TRY(hipMemcpy2DAsync(h_ids.data(), (size_t) n_used * 4, ids, (size_t) ids_stride, (size_t) n_used * 4, (size_t) n_tok, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int32_t> count((size_t) n_expert + 1, 0), order((size_t) pairs);
+        for (int64_t p = 0; p < pairs; ++p) {
+            if (h_ids[(size_t) p] < 0 || h_ids[(size_t) p] >= n_expert) return fail(MI355Q_ERR_SHAPE, "mul_mat_id: expert id %d out of range", (int) h_ids[(size_t) p]);
+            ++count[(size_t) h_ids[(size_t) p] + 1];
+        }
+        for (int64_t e = 0; e < n_expert; ++e) count[(size_t) e + 1] += count[(size_t) e];          // -> first slot of each expert
+        { std::vector<int32_t> fill(count.begin(), count.end() - 1);
+          for (int64_t p = 0; p < pairs; ++p) order[(size_t) fill[(size_t) h_ids[(size_t) p]]++] = (int32_t) p; }
+        char * wsp = (char *) workspace;
+        int32_t * d_order = (int32_t *) wsp;                 wsp += moe_align256(4 * pairs);
+        float * xg = (float *) wsp;                           wsp += moe_align256(4 * pairs * k);
+        float * yg = (float *) wsp;                           wsp += moe_align256(4 * pairs * m);
+        const size_t ws_left = workspace_bytes - (size_t) (wsp - (char *) workspace);
+        HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t) pairs * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                    // (order.data() is pageable host memory that dies with this call)
+        hipLaunchKernelGGL(k_moe_gather, dim3((unsigned) pairs), dim3(256), 0, st, (const char *) x, x_stride1, x_stride2, (int) n_used, (int) x_ne1, d_order, xg, k);
+        for (int64_t e = 0; e < n_expert; ++e) {
+            const int64_t off = count[(size_t) e], cnt = count[(size_t) e + 1] - off;
+            if (cnt == 0) continue;
+            MQ_TRY(mi355q_mul_mat(type, (const char *) w + e * expert_stride, w_stride, xg + off * k, 4 * k, yg + off * m, 4 * m, m, cnt, k, wsp, ws_left, flags, stream));
+        }
+        hipLaunchKernelGGL(k_moe_scatter, dim3((unsigned) pairs), dim3(256), 0, st, yg, d_order, y, m);
+        return hipGetLastError() == hipSuccess ? MI355Q_OK : fail(MI355Q_ERR_HIP, "mul_mat_id: grouped launch failed");
+    }
     if (is_planar(t, k) && gemv_fast_family(type) >= 0) {
         if (((uintptr_t) w | (uintptr_t) w_stride | (uintptr_t) expert_stride) & 15) return fail(MI355Q_ERR_ALIGN, "mul_mat_id: planar rows need 16-byte alignment");
         mi355q_mat mt = { type, w, w_stride, y, 4 * m, m };

@@ -317,8 +317,11 @@ def test_multi_equals_single(G, torch, orc):
 # MoE (tests/test-backend-ops.cpp:4240-4270 shapes: n_mats {4,8} x n_used {1,2,4}, m=512, k=256)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.Q8_0, oracle.Q5_K, oracle.IQ4_XS, oracle.Q4_1], ids=ids_t)
-@pytest.mark.parametrize("cfg", [(4, 1, 1), (8, 2, 1), (8, 4, 5), (4, 2, 32)], ids=str)
+@pytest.mark.parametrize("cfg", [(4, 1, 1), (8, 2, 1), (8, 4, 5), (4, 2, 32), (8, 2, 160)], ids=str)
 def test_mul_mat_id(G, torch, orc, t, cfg):
+    """(n_expert, n_used, n_tokens).  Up to 16 (token, slot) pairs every pair is one exact GEMV column with the ids read on the device;
+    above that the rows are grouped by expert and each group goes through the ordinary mul_mat tiers (csrc/api.hip), i.e. groups of
+    more than 8 rows use the matrix cores: Q4_K still reproduces the CPU arithmetic, the bf16 tier is held to the reference's op bound."""
     ne, nu, nt = cfg
     rng = np.random.default_rng(17 * t + ne + nu + nt)
     for K, M in ((256, 512), (2048, 96)):
@@ -328,7 +331,12 @@ def test_mul_mat_id(G, torch, orc, t, cfg):
         for b1 in sorted({1, nu}):
             b = rng.uniform(-1, 1, (nt, b1, K)).astype(np.float32)
             y = G.mul_mat_id(w, torch.from_numpy(b).cuda(), torch.from_numpy(ids).cuda()).cpu().numpy()
-            check_close(y, orc.mul_mat_id(t, as_, b, ids, M, K, ne), f"{ids_t(t)} {cfg} K={K} b1={b1}")
+            ref = orc.mul_mat_id(t, as_, b, ids, M, K, ne)
+            biggest = int(np.bincount(ids.ravel(), minlength=ne).max())
+            if nu * nt >= 17 and t != oracle.Q4_K and on_mfma_tier(G, t, K, biggest) and M % 4 == 0:
+                assert np.isfinite(y).all() and nmse(y, ref) <= 5e-4, f"{ids_t(t)} {cfg} K={K} b1={b1}"
+            else:
+                check_close(y, ref, f"{ids_t(t)} {cfg} K={K} b1={b1}")
 
 
 # ------------------------------------------------------------------------------------------------
