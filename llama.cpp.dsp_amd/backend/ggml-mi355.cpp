@@ -336,6 +336,15 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int
         mi355q_tensor ids = mi355_td(dst->src[1]);
         MQ_CHECK(mi355q_op_get_rows(&a, &ids, &d, ctx->stream));
     } break;
+    case GGML_OP_FLASH_ATTN_EXT: {                            // q = src[0], k, v, mask (optional); op_params: scale, max_bias, logit_softcap
+        float scale, max_bias, softcap;
+        memcpy(&scale, (const float *) dst->op_params + 0, sizeof(float));
+        memcpy(&max_bias, (const float *) dst->op_params + 1, sizeof(float));
+        memcpy(&softcap, (const float *) dst->op_params + 2, sizeof(float));
+        const mi355q_tensor k = mi355_td(dst->src[1]), v = mi355_td(dst->src[2]);
+        mi355q_tensor m; if (dst->src[3]) m = mi355_td(dst->src[3]);
+        MQ_CHECK(mi355q_op_flash_attn_ext(&a, &k, &v, dst->src[3] ? &m : nullptr, &d, scale, max_bias, softcap, ctx->stream));
+    } break;
     case GGML_OP_SCALE: {
         float sc; memcpy(&sc, dst->op_params, sizeof(float));
         MQ_CHECK(mi355q_op_scale(&a, &d, sc, ctx->stream));
@@ -576,7 +585,7 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
             mi355_glue_op(ctx, node);
         } break;
         case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
-        case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE:
+        case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE: case GGML_OP_FLASH_ATTN_EXT:
             mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
@@ -783,6 +792,14 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
         if (mode != 0 && mode != 2) return false;                 // normal and neox; mrope / vision stay on the CPU
         if (op->src[2] && op->src[2]->type != GGML_TYPE_F32) return false;
         return a->ne[0] % 2 == 0;
+    }
+    case GGML_OP_FLASH_ATTN_EXT: {                            // f16 KV cache, f32 queries, f16 mask; quantized caches stay on the CPU
+        const struct ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
+        if (q->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+        if (!mi355_operand_ok(q) || !mi355_operand_ok(k) || !mi355_operand_ok(v) || (m && !mi355_operand_ok(m))) return false;
+        if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || !ggml_is_contiguous(op)) return false;
+        if (m && (m->type != GGML_TYPE_F16 || m->nb[0] != 2 || m->ne[0] < k->ne[1] || m->ne[1] < q->ne[1] || m->ne[2] != 1 || m->ne[3] != 1)) return false;
+        return k->ne[0] <= 256 && v->ne[0] <= 256 && k->ne[1] >= 1 && k->ne[1] <= 36864 && q->ne[2] <= 65535 && q->ne[3] <= 65535;
     }
     case GGML_OP_SOFT_MAX: {
         const struct ggml_tensor * a = op->src[0];

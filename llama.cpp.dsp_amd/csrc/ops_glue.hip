@@ -357,6 +357,91 @@ __global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const Tensor
     }
 }
 
+// ---- FLASH_ATTN_EXT, f16 K / V, f32 Q: one workgroup per (query row, head, batch) -----------------------------------
+// dst[:, h, t, b] = softmax_j(softcap(scale * k_j . q) + slope_h * mask[t][j]) . v_j      (ggml-cpu/ops.cpp:6690-6905; q is rounded to
+// f16 before the dot products as the CPU's vec_dot_type conversion does).  Two passes over a row of scores held in LDS instead of the
+// CPU's online update (same mathematics; the CPU accumulates V in f16, this kernel in f32).  Written for correctness and decode sizes:
+// every workgroup streams its head's K and V once.
+constexpr int FA_THREADS = 1024, FA_WAVES = FA_THREADS / 64;      // 16 waves: a decode step has only n_head workgroups, each must hide its own latency
+__global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, const TensorD k, const TensorD v, const TensorD m, int has_mask,
+                                                        const TensorD d, float scale, float max_bias, float softcap, float m0, float m1, uint32_t n_head_log2) {
+    extern __shared__ __attribute__((aligned(16))) float fa_s[];              // [n_kv] scores -> probabilities, then [256] partial sums
+    __shared__ float red[2 * FA_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int64_t DK = k.ne[0], DV = v.ne[0], n_kv = k.ne[1];
+    const int64_t hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), bk = b / (q.ne[3] / k.ne[3]), bv = b / (q.ne[3] / v.ne[3]);
+    const float * qp = (const float *) (q.data + t * q.nb[1] + h * q.nb[2] + b * q.nb[3]);
+    const float slope = max_bias > 0.0f ? ((uint32_t) h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half * mp = has_mask ? (const __half *) (m.data + t * m.nb[1]) : nullptr;
+    float qh[4];                                                             // head sizes up to 256: 4 elements per lane
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qh[u] = lane + 64 * u < DK ? __half2float(__float2half_rn(qp[lane + 64 * u])) : 0.0f;
+    // ---- scores
+    constexpr int JB = 8;                                                   // rows per trip: their loads are in flight together
+    for (int64_t j0 = wave; j0 < n_kv; j0 += FA_WAVES * JB) {
+        float kv[JB][4];
+#pragma unroll
+        for (int c = 0; c < JB; ++c) {
+            const int64_t j = j0 + FA_WAVES * c < n_kv ? j0 + FA_WAVES * c : j0;
+            const __half * kp = (const __half *) (k.data + j * k.nb[1] + hk * k.nb[2] + bk * k.nb[3]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kv[c][u] = lane + 64 * u < DK ? __half2float(kp[lane + 64 * u]) : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < JB; ++c) {
+            const int64_t j = j0 + FA_WAVES * c;
+            float s = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += kv[c][u] * qh[u];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0 && j < n_kv) {
+                s *= scale;
+                if (softcap != 0.0f) s = softcap * tanhf(s);
+                if (mp) s += slope * __half2float(mp[j]);
+                fa_s[j] = s;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- row maximum, exponentials, their sum
+    float mx = -INFINITY;
+    for (int64_t j = tid; j < n_kv; j += FA_THREADS) mx = fmaxf(mx, fa_s[j]);
+    mx = wave_max_f32(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w2 = 1; w2 < FA_WAVES; ++w2) mx = fmaxf(mx, red[w2]);
+    float sum = 0.0f;
+    for (int64_t j = tid; j < n_kv; j += FA_THREADS) { const float e = expf(fa_s[j] - mx); fa_s[j] = e; sum += e; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) red[FA_WAVES + wave] = sum;
+    __syncthreads();
+    sum = 0.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < FA_WAVES; ++w2) sum += red[FA_WAVES + w2];
+    // ---- out[e] = sum_j p_j v[j][e] / sum: thread = (group g, element e); the groups split the kv positions
+    const int per = (int) DV, groups = FA_THREADS / per, g = tid / per, e = tid - g * per;
+    float acc = 0.0f;
+    if (g < groups) {
+        const char * vb = v.data + hv * v.nb[2] + bv * v.nb[3] + 2 * (int64_t) e;
+#pragma unroll 8
+        for (int64_t j = g; j < n_kv; j += groups) acc += fa_s[j] * __half2float(*(const __half *) (vb + j * v.nb[1]));
+    }
+    __syncthreads();                                                        // everyone is done reading the probabilities
+    float * part = fa_s;                                                     // (at least FA_THREADS floats of LDS are guaranteed by the launcher)
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < per) {
+        float o = 0.0f;
+        for (int gg = 0; gg < groups; ++gg) o += part[gg * per + tid];
+        *(float *) (d.data + tid * d.nb[0] + h * d.nb[1] + t * d.nb[2] + b * d.nb[3]) = o * (1.0f / sum);
+    }
+}
+
 // ---- GET_ROWS (f32 / f16 rows -> f32): dst[:, i10, i11, i12] = src0[:, ids[i10, i11, i12], i11, i12]   ops.cpp:4272-4311 -------
 __global__ void __launch_bounds__(256) k_get_rows(const TensorD a, const char * ids, int64_t nb10, int64_t nb11, int64_t nb12,
                                                   int64_t ne10, int64_t ne11, const TensorD d, int64_t n) {
@@ -590,6 +675,38 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
     const int64_t groups_per_col = (dst->ne[0] + MMF_ROWS - 1) / MMF_ROWS, n_groups = groups_per_col * dst->ne[1] * dst->ne[2] * dst->ne[3];
     if ((n_groups + 3) / 4 > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: too many outputs");
     hipLaunchKernelGGL(k_mul_mat_f, dim3((unsigned) ((n_groups + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n_groups, groups_per_col);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, const mi355q_tensor * v, const mi355q_tensor * mask,
+                             const mi355q_tensor * dst, float scale, float max_bias, float logit_softcap, void * stream) {
+    if (!q || !k || !v || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: null tensor");
+    if (q->type != 0 || k->type != 1 || v->type != 1 || dst->type != 0 || (mask && mask->type != 1)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q f32, k / v / mask f16, dst f32");
+    const int64_t DK = k->ne[0], DV = v->ne[0], n_kv = k->ne[1], N = q->ne[1], n_head = q->ne[2], nb3 = q->ne[3];
+    if (q->ne[0] != DK || v->ne[1] != n_kv || k->ne[2] <= 0 || v->ne[2] <= 0 || n_head % k->ne[2] || n_head % v->ne[2] || k->ne[3] <= 0 || v->ne[3] <= 0 ||
+        nb3 % k->ne[3] || nb3 % v->ne[3] || dst->ne[0] != DV || dst->ne[1] != n_head || dst->ne[2] != N || dst->ne[3] != nb3)
+        OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: q [DK, N, H, B], k [DK, n_kv, Hk, Bk], v [DV, n_kv, Hv, Bv], dst [DV, H, N, B]");
+    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: innermost dimensions must be contiguous");
+    if (mask && (mask->ne[0] < n_kv || mask->ne[1] < N || mask->nb[0] != 2)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: mask f16 [>= n_kv, >= N]");
+    if (DK > 256 || DV > 256 || DK < 1 || DV < 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: head sizes up to 256");
+    if (n_kv > 36864) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: n_kv > 36864 (one row of scores lives in LDS)");
+    if (N == 0 || n_head == 0 || nb3 == 0) return MI355Q_OK;
+    if (n_kv == 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: empty KV window");
+    if (n_head > 65535 || nb3 > 65535) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: too many heads / batches");
+    if (logit_softcap != 0.0f) scale /= logit_softcap;                          // ops.cpp:6757-6759
+    uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= (uint32_t) n_head) n_head_log2 *= 2;
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    const size_t lds = (size_t) (n_kv > FA_THREADS ? n_kv : FA_THREADS) * 4;
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024) {
+        int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute((const void *) k_flash_attn_ext, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "op_flash_attn_ext: LDS attribute");
+            attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_flash_attn_ext, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
+                       to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2);
     OPS_LAUNCHED();
 }
 

@@ -13,6 +13,7 @@
 //
 //   GGML_BACKEND_PATH=.../libggml-mi355.so layer_parity [n_tokens] [device] [small|8b] [steps] [iters]
 //     steps > 1 : a decode loop -- step t appends n_tokens positions at n_past + t*n_tokens; every step is compared with the CPU.
+//     LAYER_PARITY_FA=1    : build the layer as llama.cpp does with -fa 1 (one FLASH_ATTN_EXT node, f16 mask, window padded to 256).
 //     LAYER_PARITY_TRACE=1 : keep every intermediate and print the per-node NMSE of the steps whose output differs.
 //     iters > 0 : afterwards, time `iters` graph_compute calls of the last step's graph on both backends.
 // exit code 0 = all nodes supported and every step's NMSE(out) <= 5e-4, NMSE(k cache), NMSE(v cache) <= 1e-6.
@@ -30,7 +31,7 @@
 #include "ggml-alloc.h"
 #include "ggml-backend.h"
 
-struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_ctx = 128, n_past = 20; };
+struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_ctx = 128, n_past = 20; bool fa = false; };
 
 struct Model {                       // persistent: weights and the KV cache of the layer
     ggml_context * ctx = nullptr; ggml_backend_buffer_t buf = nullptr;
@@ -63,10 +64,10 @@ static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens
     ggml_init_params ip = { ggml_tensor_overhead() * 256 + ggml_graph_overhead(), nullptr, true };
     ggml_context * c = S.ctx = ggml_init(ip);
     const int n_embd_kv = d.n_head_kv * d.hd;
-    const int n_kv = S.n_kv = GGML_PAD(n_past + n_tokens, 32);                        // the attended window is padded (masked beyond the data)
+    const int n_kv = S.n_kv = GGML_PAD(n_past + n_tokens, d.fa ? 256 : 32);            // the attended window is padded (masked beyond the data); -fa pads to 256
     S.x    = ggml_new_tensor_2d(c, GGML_TYPE_F32, d.n_embd, n_tokens);  ggml_set_input(S.x);
     S.pos  = ggml_new_tensor_1d(c, GGML_TYPE_I32, n_tokens);            ggml_set_input(S.pos);
-    S.mask = ggml_new_tensor_2d(c, GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, 32)); ggml_set_input(S.mask);
+    S.mask = ggml_new_tensor_2d(c, d.fa ? GGML_TYPE_F16 : GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, d.fa ? 64 : 32)); ggml_set_input(S.mask);   // (-fa: f16 mask, llama-graph.cpp:1211-1232)
 
     const float eps = 1e-5f, kq_scale = 1.0f / sqrtf((float) d.hd);
     // --- attention norm, projections, rope (llm_build_llama)
@@ -80,16 +81,27 @@ static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens
     // --- store k, v in the cache (llama_kv_cache_unified cpy_k / cpy_v; V transposed when flash attention is off)
     ggml_tensor * k_view = ggml_view_1d(c, M.kc, (int64_t) n_tokens * n_embd_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv) * n_past);
     ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_reshape_2d(c, K, n_embd_kv, n_tokens), k_view));
-    ggml_tensor * v_view = ggml_view_2d(c, M.vc, n_tokens, n_embd_kv, d.n_ctx * ggml_element_size(M.vc), n_past * ggml_element_size(M.vc));
-    ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_transpose(c, ggml_reshape_2d(c, V, n_embd_kv, n_tokens)), v_view));
-    // --- attention (build_attn_mha)
     ggml_tensor * q = ggml_permute(c, Q, 0, 2, 1, 3);
     ggml_tensor * k = ggml_view_3d(c, M.kc, d.hd, n_kv, d.n_head_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv), ggml_row_size(GGML_TYPE_F16, d.hd), 0);
-    ggml_tensor * kq = ggml_mul_mat(c, k, q);
-    kq = ggml_soft_max_ext(c, kq, S.mask, kq_scale, 0.0f);
-    ggml_tensor * v = ggml_view_3d(c, M.vc, n_kv, d.hd, d.n_head_kv, ggml_element_size(M.vc) * d.n_ctx, ggml_element_size(M.vc) * d.n_ctx * d.hd, 0);
-    ggml_tensor * kqv = ggml_mul_mat(c, v, kq);
-    cur = ggml_cont_2d(c, ggml_permute(c, kqv, 0, 2, 1, 3), d.n_embd, n_tokens);
+    if (d.fa) {
+        // --- -fa 1 (build_attn_mha, llama-graph.cpp:1211-1232): V is stored like K (one row per position) and one FLASH_ATTN_EXT node
+        // replaces KQ, SOFT_MAX, KQV and the CONT
+        ggml_tensor * v_view = ggml_view_1d(c, M.vc, (int64_t) n_tokens * n_embd_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv) * n_past);
+        ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_reshape_2d(c, V, n_embd_kv, n_tokens), v_view));
+        ggml_tensor * v = ggml_view_3d(c, M.vc, d.hd, n_kv, d.n_head_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv), ggml_row_size(GGML_TYPE_F16, d.hd), 0);
+        cur = ggml_flash_attn_ext(c, q, k, v, S.mask, kq_scale, 0.0f, 0.0f);
+        ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
+        cur = ggml_reshape_2d(c, cur, d.n_embd, n_tokens);
+    } else {
+        ggml_tensor * v_view = ggml_view_2d(c, M.vc, n_tokens, n_embd_kv, d.n_ctx * ggml_element_size(M.vc), n_past * ggml_element_size(M.vc));
+        ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_transpose(c, ggml_reshape_2d(c, V, n_embd_kv, n_tokens)), v_view));
+        // --- attention (build_attn_mha)
+        ggml_tensor * kq = ggml_mul_mat(c, k, q);
+        kq = ggml_soft_max_ext(c, kq, S.mask, kq_scale, 0.0f);
+        ggml_tensor * v = ggml_view_3d(c, M.vc, n_kv, d.hd, d.n_head_kv, ggml_element_size(M.vc) * d.n_ctx, ggml_element_size(M.vc) * d.n_ctx * d.hd, 0);
+        ggml_tensor * kqv = ggml_mul_mat(c, v, kq);
+        cur = ggml_cont_2d(c, ggml_permute(c, kqv, 0, 2, 1, 3), d.n_embd, n_tokens);
+    }
     cur = ggml_mul_mat(c, M.wo, cur);
     // --- residual, ffn (build_ffn LLM_FFN_SILU, LLM_FFN_PAR)
     ggml_tensor * ffn_inp = ggml_add(c, cur, S.x);
@@ -127,7 +139,9 @@ int main(int argc, char ** argv) {
     ggml_backend_t be_dev = ggml_backend_dev_init(dev, nullptr);
     ggml_backend_t be_cpu = ggml_backend_init_by_type(GGML_BACKEND_DEVICE_TYPE_CPU, nullptr);
     Dims d;
+    d.fa = getenv("LAYER_PARITY_FA") != nullptr;               // the -fa 1 form of the layer (FLASH_ATTN_EXT, V cache not transposed)
     if (big) { d.n_embd = 4096; d.n_head = 32; d.n_head_kv = 8; d.hd = 128; d.n_ff = 14336; d.n_ctx = 1024; d.n_past = 500; }
+    if (d.fa && d.n_ctx < 512) d.n_ctx = 512;
     if (d.n_past + steps * n_tokens > d.n_ctx) { fprintf(stderr, "too many steps for n_ctx\n"); return 3; }
     Model mr = make_model(d, be_cpu), mt = make_model(d, be_dev);
     ggml_gallocr_t ga_cpu = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be_cpu));
@@ -181,9 +195,10 @@ int main(int argc, char ** argv) {
         }
         { auto x = randv((size_t) d.n_embd * n_tokens, 1.0f); set_both(sr.x, st.x, x.data(), x.size() * 4); }
         { std::vector<int32_t> p(n_tokens); for (int i = 0; i < n_tokens; ++i) p[i] = n_past + i; set_both(sr.pos, st.pos, p.data(), p.size() * 4); }
-        { std::vector<float> m((size_t) sr.n_kv * GGML_PAD(n_tokens, 32), -INFINITY);       // causal mask over the padded window
+        { std::vector<float> m((size_t) sr.n_kv * GGML_PAD(n_tokens, d.fa ? 64 : 32), -INFINITY);       // causal mask over the padded window
           for (int i = 0; i < n_tokens; ++i) for (int j = 0; j <= n_past + i; ++j) m[(size_t) i * sr.n_kv + j] = 0.0f;
-          set_both(sr.mask, st.mask, m.data(), m.size() * 4); }
+          if (d.fa) { std::vector<ggml_fp16_t> h(m.size()); ggml_fp32_to_fp16_row(m.data(), h.data(), m.size()); set_both(sr.mask, st.mask, h.data(), h.size() * 2); }
+          else set_both(sr.mask, st.mask, m.data(), m.size() * 4); }
         if (ggml_backend_graph_compute(be_cpu, sr.gf) != GGML_STATUS_SUCCESS || ggml_backend_graph_compute(be_dev, st.gf) != GGML_STATUS_SUCCESS) {
             fprintf(stderr, "graph_compute failed\n"); return 4;
         }

@@ -146,3 +146,44 @@ def test_fused_norm_and_activation_equal_separate_ops(G, torch):
         assert torch.equal(s, s_sep) and torch.equal(y, y_sep)
         # silu(a) * b
         assert torch.equal(G.op_unary_mul(G.UNARY_SILU, a, b), G.op_bin_bcast(G.OP_MUL, G.op_unary(G.UNARY_SILU, a), b))
+
+
+@pytest.mark.parametrize("cfg", [(128, 128, 8, 2, 1, 512, 0.0, 0.0), (64, 64, 4, 4, 7, 96, 0.0, 0.0), (128, 128, 8, 8, 3, 300, 8.0, 0.0),
+                                 (80, 80, 4, 1, 2, 64, 0.0, 10.0), (256, 256, 2, 2, 1, 1000, 0.0, 0.0), (128, 128, 32, 8, 1, 4096, 0.0, 0.0)], ids=str)
+def test_flash_attn_ext(G, torch, cfg):
+    """GGML_OP_FLASH_ATTN_EXT for an f16 KV cache against a float64 restatement of ggml-cpu/ops.cpp:6690-6905 (q rounded to f16 before
+    the dot products; causal f16 mask with -inf; GQA; ALiBi slopes; logit soft-capping).  The reference's own harness checks the same op
+    through the plugin (tests/test_plugin.py, FLASH_ATTN_EXT)."""
+    DK, DV, H, Hk, N, n_kv, max_bias, softcap = cfg
+    rng = np.random.default_rng(DK + H + N + n_kv)
+    q = rng.standard_normal((1, H, N, DK)).astype(np.float32)
+    k = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float16)
+    v = rng.standard_normal((1, Hk, n_kv, DV)).astype(np.float16)
+    mask = np.zeros((32 * ((N + 31) // 32), n_kv), np.float16)
+    for t in range(N):
+        mask[t, n_kv - N + t + 1:] = -np.inf
+    mask[:N] += (rng.standard_normal((N, n_kv)) * 0.1).astype(np.float16) * (max_bias > 0)      # ALiBi-like finite biases
+    scale = 1.0 / np.sqrt(DK)
+    y = G.op_flash_attn_ext(dev(torch, q), dev(torch, k), dev(torch, v), dev(torch, mask), scale, max_bias, softcap).cpu().numpy()
+    # float64 restatement
+    n2 = 1
+    while 2 * n2 <= H:
+        n2 *= 2
+    m0, m1 = 2.0 ** (-max_bias / n2), 2.0 ** (-(max_bias / 2.0) / n2)
+    ref = np.zeros((1, N, H, DV))
+    qh = q.astype(np.float16).astype(np.float64)
+    for h in range(H):
+        hk = h // (H // Hk)
+        slope = (m0 ** (h + 1) if h < n2 else m1 ** (2 * (h - n2) + 1)) if max_bias > 0 else 1.0
+        s = qh[0, h] @ k[0, hk].astype(np.float64).T                      # [N, n_kv]
+        s = s * (scale / softcap if softcap else scale)
+        if softcap:
+            s = softcap * np.tanh(s)
+        s = s + slope * mask[:N].astype(np.float64)
+        s = s - s.max(axis=1, keepdims=True)
+        p = np.exp(s)
+        p /= p.sum(axis=1, keepdims=True)
+        ref[0, :, h] = p @ v[0, hk].astype(np.float64)
+    assert np.isfinite(y).all()
+    err = np.abs(y - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (cfg, err)

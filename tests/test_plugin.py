@@ -79,7 +79,7 @@ def test_reference_test_backend_ops(op):
 @pytest.mark.gpu
 @needs_plugin
 @pytest.mark.parametrize("op", ["ADD", "SUB", "MUL", "DIV", "RMS_NORM", "SILU", "RELU", "SIGMOID", "TANH", "NEG", "ABS",
-                                "CPY", "CONT", "DUP", "SOFT_MAX", "ROPE", "GET_ROWS", "SCALE"])
+                                "CPY", "CONT", "DUP", "SOFT_MAX", "ROPE", "GET_ROWS", "SCALE", "FLASH_ATTN_EXT"])
 def test_reference_test_backend_ops_residency(op):
     """The residency ops through the reference's own harness: every case the plugin accepts must pass the
     harness' NMSE check against the ggml CPU backend; cases it declines are reported 'not supported' (never FAIL)."""
@@ -166,3 +166,19 @@ def test_fused_nodes_bit_identical_to_separate_nodes(n_tokens):
     assert digests[0] == digests[1], digests
     assert saved[1] == (0, 0, 0, 0, 0)
     assert saved[0][0] + saved[0][4] > 0 and saved[0][1] > 0 and saved[0][2] > 0
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("n_tokens", [1, 3])
+def test_decode_layer_with_flash_attention(n_tokens):
+    """The same decoder layer built the way llama.cpp builds it with -fa 1 (one GGML_OP_FLASH_ATTN_EXT node on the f16 cache, V not
+    transposed, f16 mask, window padded to 256): resident (no node refused) and equal to the CPU backend over a 12-step decode loop."""
+    exe = _harness().parent / "layer_parity"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/*/layer_parity not built")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN), LAYER_PARITY_FA="1")
+    r = subprocess.run([str(exe), str(n_tokens), "MI355_0", "small", "12"], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 refused by MI355_0" in r.stdout and "LAYER PARITY OK" in r.stdout
