@@ -364,16 +364,20 @@ __global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const Tensor
 // every workgroup streams its head's K and V once.
 constexpr int FA_THREADS = 1024, FA_WAVES = FA_THREADS / 64;      // 16 waves: a decode step has only n_head workgroups, each must hide its own latency
 __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, const TensorD k, const TensorD v, const TensorD m, int has_mask,
-                                                        const TensorD d, float scale, float max_bias, float softcap, float m0, float m1, uint32_t n_head_log2) {
+                                                        const TensorD d, float scale, float max_bias, float softcap, float m0, float m1, uint32_t n_head_log2,
+                                                        int n_split, float * __restrict__ part_out) {
     extern __shared__ __attribute__((aligned(16))) float fa_s[];              // [n_kv] scores -> probabilities, then [256] partial sums
     __shared__ float red[2 * FA_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int64_t DK = k.ne[0], DV = v.ne[0], n_kv = k.ne[1];
+    // n_split > 1: the KV range is cut in n_split pieces, one workgroup each (a decode step has only n_head rows: more workgroups, shorter
+    // chains); each writes its unnormalised sum, maximum and sum of exponentials, k_flash_attn_combine merges them
+    const int64_t t = blockIdx.x / n_split, sp = blockIdx.x - t * n_split, h = blockIdx.y, b = blockIdx.z;
+    const int64_t DK = k.ne[0], DV = v.ne[0], n_kv_all = k.ne[1];
+    const int64_t chunk = (n_kv_all + n_split - 1) / n_split, j_lo = sp * chunk, n_kv = j_lo < n_kv_all ? (j_lo + chunk <= n_kv_all ? chunk : n_kv_all - j_lo) : 0;
     const int64_t hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), bk = b / (q.ne[3] / k.ne[3]), bv = b / (q.ne[3] / v.ne[3]);
     const float * qp = (const float *) (q.data + t * q.nb[1] + h * q.nb[2] + b * q.nb[3]);
     const float slope = max_bias > 0.0f ? ((uint32_t) h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
-    const __half * mp = has_mask ? (const __half *) (m.data + t * m.nb[1]) : nullptr;
+    const __half * mp = has_mask ? (const __half *) (m.data + t * m.nb[1]) + j_lo : nullptr;
     float qh[4];                                                             // head sizes up to 256: 4 elements per lane
 #pragma unroll
     for (int u = 0; u < 4; ++u) qh[u] = lane + 64 * u < DK ? __half2float(__float2half_rn(qp[lane + 64 * u])) : 0.0f;
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
 #pragma unroll
         for (int c = 0; c < JB; ++c) {
             const int64_t j = j0 + FA_WAVES * c < n_kv ? j0 + FA_WAVES * c : j0;
-            const __half * kp = (const __half *) (k.data + j * k.nb[1] + hk * k.nb[2] + bk * k.nb[3]);
+            const __half * kp = (const __half *) (k.data + (j_lo + j) * k.nb[1] + hk * k.nb[2] + bk * k.nb[3]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) kv[c][u] = lane + 64 * u < DK ? __half2float(kp[lane + 64 * u]) : 0.0f;
         }
@@ -415,7 +419,7 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
 #pragma unroll
     for (int w2 = 1; w2 < FA_WAVES; ++w2) mx = fmaxf(mx, red[w2]);
     float sum = 0.0f;
-    for (int64_t j = tid; j < n_kv; j += FA_THREADS) { const float e = expf(fa_s[j] - mx); fa_s[j] = e; sum += e; }
+    for (int64_t j = tid; j < n_kv; j += FA_THREADS) { const float e = mx == -INFINITY ? 0.0f : expf(fa_s[j] - mx); fa_s[j] = e; sum += e; }   // (a fully masked piece contributes nothing)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if (lane == 0) red[FA_WAVES + wave] = sum;
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
     const int per = (int) DV, groups = FA_THREADS / per, g = tid / per, e = tid - g * per;
     float acc = 0.0f;
     if (g < groups) {
-        const char * vb = v.data + hv * v.nb[2] + bv * v.nb[3] + 2 * (int64_t) e;
+        const char * vb = v.data + j_lo * v.nb[1] + hv * v.nb[2] + bv * v.nb[3] + 2 * (int64_t) e;
 #pragma unroll 8
         for (int64_t j = g; j < n_kv; j += groups) acc += fa_s[j] * __half2float(*(const __half *) (vb + j * v.nb[1]));
     }
@@ -438,9 +442,30 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
     if (tid < per) {
         float o = 0.0f;
         for (int gg = 0; gg < groups; ++gg) o += part[gg * per + tid];
-        *(float *) (d.data + tid * d.nb[0] + h * d.nb[1] + t * d.nb[2] + b * d.nb[3]) = o * (1.0f / sum);
+        if (n_split == 1) *(float *) (d.data + tid * d.nb[0] + h * d.nb[1] + t * d.nb[2] + b * d.nb[3]) = o * (1.0f / sum);
+        else {
+            float * pr = part_out + ((((int64_t) b * gridDim.y + h) * (gridDim.x / n_split) + t) * n_split + sp) * (DV + 2);
+            pr[tid] = o;
+            if (tid == 0) { pr[DV] = mx; pr[DV + 1] = sum; }
+        }
     }
 }
+
+// merge the pieces of a split row: out = sum_s e^(m_s - M) o_s / sum_s e^(m_s - M) l_s
+__global__ void __launch_bounds__(256) k_flash_attn_combine(const float * __restrict__ part, int n_split, int64_t DV, int64_t N, const TensorD d) {
+    const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const float * pr = part + (((b * gridDim.y + h) * N + t) * n_split) * (DV + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < n_split; ++s) M = fmaxf(M, pr[s * (DV + 2) + DV]);
+    float den = 0.0f;
+    for (int s = 0; s < n_split; ++s) { const float ms = pr[s * (DV + 2) + DV]; den += (ms == -INFINITY ? 0.0f : expf(ms - M)) * pr[s * (DV + 2) + DV + 1]; }
+    for (int64_t e = threadIdx.x; e < DV; e += 256) {
+        float o = 0.0f;
+        for (int s = 0; s < n_split; ++s) { const float ms = pr[s * (DV + 2) + DV]; o += (ms == -INFINITY ? 0.0f : expf(ms - M)) * pr[s * (DV + 2) + e]; }
+        *(float *) (d.data + e * d.nb[0] + h * d.nb[1] + t * d.nb[2] + b * d.nb[3]) = o / den;
+    }
+}
+
 
 // ---- GET_ROWS (f32 / f16 rows -> f32): dst[:, i10, i11, i12] = src0[:, ids[i10, i11, i12], i11, i12]   ops.cpp:4272-4311 -------
 __global__ void __launch_bounds__(256) k_get_rows(const TensorD a, const char * ids, int64_t nb10, int64_t nb11, int64_t nb12,
@@ -678,8 +703,14 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
     OPS_LAUNCHED();
 }
 
+size_t mi355q_op_flash_attn_ext_workspace(int64_t dv, int64_t n_q, int64_t n_head, int64_t n_batch) {
+    if (n_q * n_head * n_batch > 256) return 0;                             // many rows: one workgroup per row fills the chip
+    return (size_t) (8 * n_q * n_head * n_batch * (dv + 2) * 4);            // up to 8 pieces per row
+}
+
 int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, const mi355q_tensor * v, const mi355q_tensor * mask,
-                             const mi355q_tensor * dst, float scale, float max_bias, float logit_softcap, void * stream) {
+                             const mi355q_tensor * dst, float scale, float max_bias, float logit_softcap,
+                             void * workspace, size_t workspace_bytes, void * stream) {
     if (!q || !k || !v || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: null tensor");
     if (q->type != 0 || k->type != 1 || v->type != 1 || dst->type != 0 || (mask && mask->type != 1)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q f32, k / v / mask f16, dst f32");
     const int64_t DK = k->ne[0], DV = v->ne[0], n_kv = k->ne[1], N = q->ne[1], n_head = q->ne[2], nb3 = q->ne[3];
@@ -696,7 +727,12 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
     if (logit_softcap != 0.0f) scale /= logit_softcap;                          // ops.cpp:6757-6759
     uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= (uint32_t) n_head) n_head_log2 *= 2;
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
-    const size_t lds = (size_t) (n_kv > FA_THREADS ? n_kv : FA_THREADS) * 4;
+    // few rows (decode): split the KV range so that the chip is not left to n_head workgroups with long dependent chains
+    int n_split = 1;
+    if (N * n_head * nb3 <= 256 && n_kv >= 256) { n_split = (int) ((n_kv + 127) / 128); if (n_split > 8) n_split = 8; }
+    if (n_split > 1 && (!workspace || workspace_bytes < (size_t) (n_split * N * n_head * nb3 * (DV + 2) * 4))) n_split = 1;
+    const int64_t chunk = (n_kv + n_split - 1) / n_split;
+    const size_t lds = (size_t) (chunk > FA_THREADS ? chunk : FA_THREADS) * 4;
     static bool attr_set[64] = {};
     if (lds > 48 * 1024) {
         int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
@@ -705,8 +741,12 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
             attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(k_flash_attn_ext, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
-                       to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2);
+    hipLaunchKernelGGL(k_flash_attn_ext, dim3((unsigned) (N * n_split), (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
+                       to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2,
+                       n_split, (float *) workspace);
+    if (n_split > 1)
+        hipLaunchKernelGGL(k_flash_attn_combine, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(256), 0, (hipStream_t) stream,
+                           (const float *) workspace, n_split, DV, N, to_d(dst));
     OPS_LAUNCHED();
 }
 

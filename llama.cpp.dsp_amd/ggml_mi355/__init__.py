@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
     "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale", "mi355q_op_cpy_indirect",
     "mi355q_graph_capture_begin", "mi355q_graph_capture_end", "mi355q_graph_launch", "mi355q_graph_destroy",
-    "mi355q_op_add_rms_norm_mul", "mi355q_op_unary_mul", "mi355q_op_flash_attn_ext",
+    "mi355q_op_add_rms_norm_mul", "mi355q_op_unary_mul", "mi355q_op_flash_attn_ext", "mi355q_op_flash_attn_ext_workspace",
 ]
 
 
@@ -130,7 +130,8 @@ def lib() -> C.CDLL:
     L.mi355q_op_cpy.argtypes = [TP, TP, vp]
     L.mi355q_op_add_rms_norm_mul.argtypes = [TP, TP, TP, vp, TP, C.c_float, vp]
     L.mi355q_op_unary_mul.argtypes = [i32, TP, TP, TP, vp]
-    L.mi355q_op_flash_attn_ext.argtypes = [TP, TP, TP, TP, TP, C.c_float, C.c_float, C.c_float, vp]
+    L.mi355q_op_flash_attn_ext.argtypes = [TP, TP, TP, TP, TP, C.c_float, C.c_float, C.c_float, vp, sz, vp]
+    L.mi355q_op_flash_attn_ext_workspace.restype = sz; L.mi355q_op_flash_attn_ext_workspace.argtypes = [i64, i64, i64, i64]
     L.mi355q_op_soft_max.argtypes = [TP, TP, TP, C.c_float, C.c_float, vp]
     L.mi355q_op_rope.argtypes = [TP, vp, vp, TP, C.POINTER(_RopeParams), vp]
     L.mi355q_op_mul_mat_f.argtypes = [TP, TP, TP, vp]
@@ -370,13 +371,16 @@ def op_unary_mul(uop: int, a, b):
     return out
 
 
-def op_flash_attn_ext(q, k, v, mask, scale: float, max_bias: float = 0.0, logit_softcap: float = 0.0):
+def op_flash_attn_ext(q, k, v, mask, scale: float, max_bias: float = 0.0, logit_softcap: float = 0.0, split: bool = True):
     """GGML_OP_FLASH_ATTN_EXT: q f32 [B, H, N, DK] (torch order), k f16 [Bk, Hk, n_kv, DK], v f16 [Bv, Hv, n_kv, DV], mask f16 [>= N, >= n_kv]
     or None -> f32 [B, N, H, DV]."""
     torch = _torch()
     out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), dtype=torch.float32, device=q.device)
+    ws, wsb = (_workspace(torch, int(lib().mi355q_op_flash_attn_ext_workspace(v.shape[3], q.shape[2], q.shape[1], q.shape[0])), q.device)
+               if split else (None, 0))
     _check(lib().mi355q_op_flash_attn_ext(C.byref(_td(q)), C.byref(_td(k)), C.byref(_td(v)), C.byref(_td(mask)) if mask is not None else None,
-                                          C.byref(_td(out)), scale, max_bias, logit_softcap, _stream(torch)), "op_flash_attn_ext")
+                                          C.byref(_td(out)), scale, max_bias, logit_softcap, ws.data_ptr() if ws is not None else None, wsb,
+                                          _stream(torch)), "op_flash_attn_ext")
     return out
 
 
