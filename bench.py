@@ -374,9 +374,11 @@ def main():
                     if grp[4] is not None:
                         w = grp[0][0]
                         g.mul_mat_id(w, xs_moe[w.K], ids_pp[(w.n_expert, int(grp[4].shape[-1]))])
-                    else:
-                        for w in grp[0]:
-                            g.mul_mat(w, xs_pp[w.K], out=ys_pp[w.M])
+                    elif len(grp[0]) == 1:
+                        g.mul_mat(grp[0][0], xs_pp[grp[0][0].K], out=ys_pp[grp[0][0].M])
+                    else:                                 # wq|wk|wv, ffn_gate|ffn_up: one call, one prepared copy of the activations
+                        g.mul_mat_multi(grp[0], xs_pp[grp[0][0].K], outs=ys_multi[id(grp)])
+            ys_multi = {id(grp): [torch.empty((Npp, w.M), dtype=torch.float32, device=device) for w in grp[0]] for grp in stage.groups if len(grp[0]) > 1}
             secs = timed(pp, 3)
             flop = 2.0 * Npp * sum(w.M * w.K * (int(grp[4].shape[-1]) if grp[4] is not None else 1) for grp in stage.groups for w in grp[0])
             out["pp512"] = {"value": round(Npp / secs, 1), "unit": "tok/s", "ms": round(1e3 * secs, 3), "TFLOPs": round(flop / secs / 1e12, 1),

@@ -399,7 +399,7 @@ static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph) {
 // captured launch graph does not remove that: profiles/round1_plugin_layer.md), so the lever is FEWER launches.  While issuing the
 // nodes the backend joins what the reference's graph builder emits as separate nodes:
 //   RMS_NORM -> MUL(weight)                    one kernel                       (build_norm, src/llama-graph.cpp)
-//   MUL_MATs on the same activations           one multi-matrix GEMV launch     (wq/wk/wv, ffn_gate/ffn_up; N <= 8)
+//   MUL_MATs on the same activations           one multi-matrix GEMV launch (N <= 8) / one shared activation image (N > 8)   (wq/wk/wv, ffn_gate/ffn_up)
 //   UNARY(SiLU) -> MUL(up)                     one kernel                       (build_ffn LLM_FFN_SILU / LLM_FFN_PAR)
 //   CONT of an already flat tensor -> MUL_MAT  the copy is skipped, the matmul reads the source
 // Every fused form performs the same f32 operations in the same order as the separate nodes (results bit-identical, checked by
@@ -464,7 +464,7 @@ struct mi355_fuser {
 static bool mi355_joinable_mat(const struct ggml_tensor * n) {
     if (n->op != GGML_OP_MUL_MAT || !mi355_is_quant(n->src[0]->type)) return false;
     const struct ggml_tensor * w = n->src[0], * x = n->src[1];
-    return x->type == GGML_TYPE_F32 && x->ne[1] <= 8 && x->ne[2] == 1 && x->ne[3] == 1 && w->ne[2] == 1 && w->ne[3] == 1 &&
+    return x->type == GGML_TYPE_F32 && x->ne[2] == 1 && x->ne[3] == 1 && w->ne[2] == 1 && w->ne[3] == 1 &&
            mi355q_weights_are_planar((int) w->type, w->ne[0]) == 1;
 }
 
@@ -502,7 +502,10 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
                         mats[q].y = (float *) o->data; mats[q].y_stride = (int64_t) o->nb[1]; mats[q].m = o->src[0]->ne[1];
                     }
                     const struct ggml_tensor * x = node->src[1];
-                    MQ_CHECK(mi355q_mul_mat_multi(mats, n, (const float *) x->data, (int64_t) x->nb[1], x->ne[1], x->ne[0], nullptr, 0, 0, ctx->stream));
+                    size_t ws = 0;                            // (prefill sizes: the matrix-core tiers share one prepared copy of the activations)
+                    for (int q = 0; q < n; ++q) { const size_t b = mi355q_mul_mat_workspace(mats[q].type, mats[q].m, x->ne[1], x->ne[0]); if (b > ws) ws = b; }
+                    void * wsp = ws ? mi355_workspace(ctx, ws) : nullptr;
+                    MQ_CHECK(mi355q_mul_mat_multi(mats, n, (const float *) x->data, (int64_t) x->nb[1], x->ne[1], x->ne[0], wsp, ws, 0, ctx->stream));
                     for (int q = 1; q < n; ++q) fz->done[(size_t) idx[q]] = 1;
                     ctx->n_fused_mats += n - 1;
                     break;

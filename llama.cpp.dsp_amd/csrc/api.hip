@@ -23,10 +23,10 @@ int launch_pack(int type, void * dst, const void * src, int64_t nrows, int64_t k
 bool mmq_supported(int type, int64_t k);
 size_t mmq_workspace(int64_t n, int64_t k);
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                    int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream);
+                    int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare);
 bool mmq_i8_supported(int type, int64_t k);
 int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                  int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream);
+                  int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare);
 
 // tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
 static bool use_mmq(int type, int64_t n, int64_t k, int flags) {
@@ -249,13 +249,22 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
         for (int i = 0; i < n_mats && ok; ++i) ok = mmq_supported(mats[i].type, k) && !(((uintptr_t) mats[i].y | (uintptr_t) mats[i].y_stride) & 15);
         if (ok) {
             // Q4_K: integer matrix cores on Q8_K-quantized activations (the CPU backend's arithmetic); the other planar types: bf16 tier
+            // Matrices of one call share the prepared activations: the integer image once for all Q4_K matrices, then (the two forms share
+            // the scratch buffer, and the stream orders them) the bf16 copy once for the rest.
             static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
-            for (int i = 0; i < n_mats; ++i) {
-                if (!no_i8 && mmq_i8_supported(mats[i].type, k) && !(((uintptr_t) x | (uintptr_t) x_stride) & 15))
-                    MQ_TRY(launch_mmq_i8(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st));
-                else
-                    MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st));
-            }
+            const bool i8_ok = !no_i8 && !(((uintptr_t) x | (uintptr_t) x_stride) & 15);
+            bool first = true;
+            for (int i = 0; i < n_mats; ++i)
+                if (i8_ok && mmq_i8_supported(mats[i].type, k)) {
+                    MQ_TRY(launch_mmq_i8(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st, first));
+                    first = false;
+                }
+            first = true;
+            for (int i = 0; i < n_mats; ++i)
+                if (!(i8_ok && mmq_i8_supported(mats[i].type, k))) {
+                    MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st, first));
+                    first = false;
+                }
             return MI355Q_OK;
         }
     }

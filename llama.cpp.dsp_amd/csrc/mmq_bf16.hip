@@ -306,14 +306,15 @@ size_t mmq_workspace(int64_t n, int64_t k) {                  // one scratch siz
 }
 
 // w: planar device rows; x f32 [n][k] (row stride x_stride); workspace >= mmq_workspace(n,k); y f32 [n][m] (y_stride % 16 == 0)
+// `prepare` = convert the activations to bf16 first (matrices multiplied with the same activations share the copy)
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream) {
+                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare) {
     if (!mmq_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (m <= 0 || n <= 0) return MI355Q_OK;
     if ((y_stride & 15) || ((uintptr_t) y & 15)) return MI355Q_ERR_ALIGN;
     const int64_t pairs = n * k / 2;
     const int cgrid = (int) ((pairs + 255) / 256 < 8192 ? (pairs + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_x_to_bf16, dim3(cgrid), dim3(256), 0, stream, x, x_stride, (uint32_t *) workspace, n, k);
+    if (prepare) hipLaunchKernelGGL(k_x_to_bf16, dim3(cgrid), dim3(256), 0, stream, x, x_stride, (uint32_t *) workspace, n, k);
     // The largest tile that still gives every CU about three workgroups: 128 x 128 amortizes the dequantization best, but a
     // pp512 matmul of a 4096-row matrix is only 128 such tiles for 256 CUs; one workgroup per CU (one wave per SIMD) hides no
     // latency at all.

@@ -248,8 +248,9 @@ size_t mmq_i8_workspace(int64_t n, int64_t k) {
 }
 
 // w: planar device rows; x f32 [n][k] (row stride x_stride, 16-byte aligned rows); workspace >= mmq_i8_workspace(n,k); y f32 [n][m]
+// `prepare` = write the activation image first; several matrices multiplied with the SAME activations (wq/wk/wv, ffn_gate/ffn_up) share one image
 int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                  float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream) {
+                  float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare) {
     if (!mmq_i8_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (m <= 0 || n <= 0) return MI355Q_OK;
     if ((x_stride & 15) || ((uintptr_t) x & 15)) return MI355Q_ERR_ALIGN;
@@ -258,7 +259,7 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
     uint8_t * xq = (uint8_t *) workspace;
     uint8_t * xs = xq + (size_t) nb * n_pad * I8Q_REC;
     float   * xd = (float *) (xs + (size_t) nb * n_pad * I8Q_XS);
-    hipLaunchKernelGGL(k_mmq_i8_prep, dim3((unsigned) nb, (unsigned) (n_pad / 4)), dim3(256), 0, stream, x, x_stride, xq, xs, xd, (int) n, (int) n_pad, nb);
+    if (prepare) hipLaunchKernelGGL(k_mmq_i8_prep, dim3((unsigned) nb, (unsigned) (n_pad / 4)), dim3(256), 0, stream, x, x_stride, xq, xs, xd, (int) n, (int) n_pad, nb);
     // 128 rows x 128 tokens per workgroup (the dequantization is shared by most tokens) when that still gives a CU 1.5 workgroups;
     // otherwise 64 x 64 (four times the workgroups, 3-4 per CU): measured at N = 512, 4096 x 4096: 47 -> 42 us, 4096 x 14336: 147 -> 128 us
     const int64_t rb = (m + 127) / 128;

@@ -16,7 +16,7 @@
 //     LAYER_PARITY_FA=1    : build the layer as llama.cpp does with -fa 1 (one FLASH_ATTN_EXT node, f16 mask, window padded to 256).
 //     LAYER_PARITY_TRACE=1 : keep every intermediate and print the per-node NMSE of the steps whose output differs.
 //     iters > 0 : afterwards, time `iters` graph_compute calls of the last step's graph on both backends.
-// exit code 0 = all nodes supported and every step's NMSE(out) <= 5e-4, NMSE(k cache), NMSE(v cache) <= 1e-6.
+// exit code 0 = all nodes supported and every step's NMSE(out) <= 5e-4, NMSE(k cache), NMSE(v cache) <= 1e-6 (5e-4 with more than 8 tokens per step).
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -214,7 +214,10 @@ int main(int argc, char ** argv) {
             printf("    node %2d %-10s ne [%5lld %5lld %3lld]  NMSE %.3e\n", i, ggml_op_desc(a), (long long) a->ne[0], (long long) a->ne[1], (long long) a->ne[2], e);
         }
         worst_out = std::fmax(worst_out, e_out); worst_kv = std::fmax(worst_kv, std::fmax(e_k, e_v));
-        ok = ok && e_out <= 5e-4 && e_k <= 1e-6 && e_v <= 1e-6 && std::isfinite(e_out);
+        // decode sizes: the projections are exact-integer GEMVs, the cache must agree to f16 rounding flips; more than 8 tokens: the
+        // matrix-core tiers (bf16 operands for Q6_K) are held to the reference's op bound
+        const double kv_tol = n_tokens > 8 ? 5e-4 : 1e-6;
+        ok = ok && e_out <= 5e-4 && e_k <= kv_tol && e_v <= kv_tol && std::isfinite(e_out);
     }
     mix(get_f16(mt.kc)); mix(get_f16(mt.vc));
     printf("%d step(s): worst NMSE out %.3e, kv cache %.3e; device output digest %016llx\n", steps, worst_out, worst_kv, (unsigned long long) digest);

@@ -304,13 +304,13 @@ def test_multi_equals_single(G, torch, orc):
     specs = [(oracle.Q4_K, 96), (oracle.Q4_K, 40), (oracle.Q6_K, 24)]
     hosts = [quantized_weights(t, m, K, rng) for t, m in specs]
     ws = [G.QWeight.from_host(t, h, m, K) for (t, m), h in zip(specs, hosts)]
-    for N in (1, 4):
+    for N in (1, 4, 64):                                   # 64: the matrix-core tiers, which share one prepared copy of the activations per call
         x = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
         multi = [y.cpu().numpy() for y in G.mul_mat_multi(ws, x)]
         for (t, m), h, w, ym in zip(specs, hosts, ws, multi):
             single = G.mul_mat(w, x).cpu().numpy()
             assert np.array_equal(single.view(np.uint32), ym.view(np.uint32))
-            check_close(ym, orc.mul_mat(t, h, x.cpu().numpy(), m, N, K))
+            check(G, t, K, N, ym, orc.mul_mat(t, h, x.cpu().numpy(), m, N, K), f"multi N={N}")
 
 
 # ------------------------------------------------------------------------------------------------
