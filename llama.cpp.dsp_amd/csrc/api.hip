@@ -27,6 +27,8 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
 bool mmq_i8_supported(int type, int64_t k);
 int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
                   int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare);
+int launch_mmq_i8_multi(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
+                        void * workspace, int n_cu, hipStream_t stream, bool prepare);
 
 // tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
 static bool use_mmq(int type, int64_t n, int64_t k, int flags) {
@@ -253,13 +255,10 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
             // the scratch buffer, and the stream orders them) the bf16 copy once for the rest.
             static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
             const bool i8_ok = !no_i8 && !(((uintptr_t) x | (uintptr_t) x_stride) & 15);
+            mi355q_mat i8m[4]; int n_i8 = 0;                 // ... and ONE grid: their row blocks are concatenated
+            for (int i = 0; i < n_mats; ++i) if (i8_ok && mmq_i8_supported(mats[i].type, k) && mats[i].m > 0) i8m[n_i8++] = mats[i];
+            if (n_i8 > 0) MQ_TRY(launch_mmq_i8_multi(i8m, n_i8, x, x_stride, n, k, workspace, cu_count(), st, true));
             bool first = true;
-            for (int i = 0; i < n_mats; ++i)
-                if (i8_ok && mmq_i8_supported(mats[i].type, k)) {
-                    MQ_TRY(launch_mmq_i8(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st, first));
-                    first = false;
-                }
-            first = true;
             for (int i = 0; i < n_mats; ++i)
                 if (!(i8_ok && mmq_i8_supported(mats[i].type, k))) {
                     MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st, first));

@@ -75,10 +75,14 @@ __device__ __forceinline__ uint32_t i8q_bf16_pair(int a, int b) {               
     return (__float_as_uint((float) a) >> 16) | (__float_as_uint((float) b) & 0xFFFF0000u);
 }
 
+// Up to 4 matrices multiplied with the same activations in ONE grid (wq|wk|wv, ffn_gate|ffn_up): their row blocks are concatenated, so a
+// 1024-row wk does not become a launch of its own that leaves most of the chip idle.  rb_begin[i] = first row block of matrix i.
+struct I8Mats { const uint8_t * w[4]; int64_t w_stride[4]; float * y[4]; int64_t y_stride[4]; int m[4]; int rb_begin[4]; };
+
 template <int RT, int TT, bool STAMPS>
 __global__ void __launch_bounds__(256, 2)
-k_mmq_i8_q4k(const uint8_t * __restrict__ w, int64_t w_stride, const uint8_t * __restrict__ xq, const uint8_t * __restrict__ xs, const float * __restrict__ xd,
-             float * __restrict__ y, int64_t y_stride, int m, int n, int n_pad, int nb, int n_tok_tiles, int total_tiles, int per_xcd) {
+k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t * __restrict__ xs, const float * __restrict__ xd,
+             int n, int n_pad, int nb, int n_tok_tiles, int total_tiles, int per_xcd) {
     constexpr int BN = 16 * TT, BM = 64 * RT;
     constexpr int XQ_BYTES = BN * I8Q_REC, XS_BYTES = BN * I8Q_XS, XD_BYTES = BN * 4, BUF = XQ_BYTES + XS_BYTES + XD_BYTES;
     constexpr int XQ_PIECES = XQ_BYTES / 1024, XS_PIECES = XS_BYTES / 1024;          // 1 KiB per wave-instruction (64 lanes x 16 B)
@@ -88,7 +92,15 @@ k_mmq_i8_q4k(const uint8_t * __restrict__ w, int64_t w_stride, const uint8_t * _
     // workgroups that share weight rows (the token tiles of one row block) are consecutive on ONE XCD: its L2 serves the re-reads
     const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (v >= total_tiles) return;
-    const int rb = v / n_tok_tiles, tt0 = v - rb * n_tok_tiles;
+    const int rb_all = v / n_tok_tiles, tt0 = v - rb_all * n_tok_tiles;
+    // which matrix (scalar selects on kernel arguments; rb_begin of unused slots is INT_MAX)
+    const int mi = (rb_all >= mats.rb_begin[1]) + (rb_all >= mats.rb_begin[2]) + (rb_all >= mats.rb_begin[3]);
+    const uint8_t * __restrict__ w = mi == 0 ? mats.w[0] : mi == 1 ? mats.w[1] : mi == 2 ? mats.w[2] : mats.w[3];
+    const int64_t w_stride = mi == 0 ? mats.w_stride[0] : mi == 1 ? mats.w_stride[1] : mi == 2 ? mats.w_stride[2] : mats.w_stride[3];
+    float * __restrict__ y = mi == 0 ? mats.y[0] : mi == 1 ? mats.y[1] : mi == 2 ? mats.y[2] : mats.y[3];
+    const int64_t y_stride = mi == 0 ? mats.y_stride[0] : mi == 1 ? mats.y_stride[1] : mi == 2 ? mats.y_stride[2] : mats.y_stride[3];
+    const int m = mi == 0 ? mats.m[0] : mi == 1 ? mats.m[1] : mi == 2 ? mats.m[2] : mats.m[3];
+    const int rb = rb_all - (mi == 0 ? 0 : mi == 1 ? mats.rb_begin[1] : mi == 2 ? mats.rb_begin[2] : mats.rb_begin[3]);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: the DMA piece loop branches on it
     const int l16 = lane & 15, kq = lane >> 4, h16 = 16 * (kq >> 1);
     const int m0 = rb * BM + wave * 16 * RT, n0 = tt0 * BN;
@@ -248,11 +260,13 @@ size_t mmq_i8_workspace(int64_t n, int64_t k) {
 }
 
 // w: planar device rows; x f32 [n][k] (row stride x_stride, 16-byte aligned rows); workspace >= mmq_i8_workspace(n,k); y f32 [n][m]
-// `prepare` = write the activation image first; several matrices multiplied with the SAME activations (wq/wk/wv, ffn_gate/ffn_up) share one image
-int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                  float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare) {
-    if (!mmq_i8_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
-    if (m <= 0 || n <= 0) return MI355Q_OK;
+// One grid for up to 4 Q4_K matrices on the same activations.  w: planar device rows; x f32 [n][k] (16-byte aligned rows);
+// workspace >= mmq_i8_workspace(n,k); y_i f32 [n][m_i].  prepare: write the activation image first.
+int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
+                        void * workspace, int n_cu, hipStream_t stream, bool prepare) {
+    if (n_mats < 1 || n_mats > 4) return MI355Q_ERR_SHAPE;
+    for (int i = 0; i < n_mats; ++i) if (!mmq_i8_supported(mt[i].type, k)) return MI355Q_ERR_UNSUPPORTED;
+    if (n <= 0) return MI355Q_OK;
     if ((x_stride & 15) || ((uintptr_t) x & 15)) return MI355Q_ERR_ALIGN;
     const int nb = (int) (k / 256);
     const int64_t n_pad = i8q_npad(n);
@@ -262,11 +276,11 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
     if (prepare) hipLaunchKernelGGL(k_mmq_i8_prep, dim3((unsigned) nb, (unsigned) (n_pad / 4)), dim3(256), 0, stream, x, x_stride, xq, xs, xd, (int) n, (int) n_pad, nb);
     // 128 rows x 128 tokens per workgroup (the dequantization is shared by most tokens) when that still gives a CU 1.5 workgroups;
     // otherwise 64 x 64 (four times the workgroups, 3-4 per CU): measured at N = 512, 4096 x 4096: 47 -> 42 us, 4096 x 14336: 147 -> 128 us
-    const int64_t rb = (m + 127) / 128;
-    const bool wide = 2 * rb * (n_pad / 128) >= 3 * (int64_t) n_cu;
-#define MI355Q_I8_LAUNCH(RT, TT, STAMPS) {                                                                                                   \
-        constexpr int bn = 16 * TT;                                                                                                \
-        const size_t lds_bytes = 2 * (size_t) (bn * (I8Q_REC + I8Q_XS + 4)); \
+    int64_t rb128 = 0; for (int i = 0; i < n_mats; ++i) rb128 += (mt[i].m + 127) / 128;
+    const bool wide = 2 * rb128 * (n_pad / 128) >= 3 * (int64_t) n_cu;
+#define MI355Q_I8_LAUNCH(RT, TT, STAMPS) {                                                                                         \
+        constexpr int bn = 16 * TT, bm = 64 * RT;                                                                                  \
+        const size_t lds_bytes = 2 * (size_t) (bn * (I8Q_REC + I8Q_XS + 4));                                                       \
         static bool attr_set[64] = {};          /* the attribute is per device: the plugin drives every visible GPU from one process */ \
         int dev_ = 0; (void) hipGetDevice(&dev_); dev_ = dev_ >= 0 && dev_ < 64 ? dev_ : 0;                                          \
         if (!attr_set[dev_]) {                                                                                                     \
@@ -274,10 +288,17 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
                 return MI355Q_ERR_HIP;                                                                                             \
             attr_set[dev_] = true;                                                                                                 \
         }                                                                                                                          \
-        const int n_tok_tiles = (int) (n_pad / bn), total = (int) (((m + 64 * RT - 1) / (64 * RT)) * n_tok_tiles), per_xcd = (total + 7) / 8; \
-        hipLaunchKernelGGL((k_mmq_i8_q4k<RT, TT, STAMPS>), dim3((unsigned) (8 * per_xcd)), dim3(256), lds_bytes, stream, (const uint8_t *) w, w_stride, \
-                           (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, y, y_stride, (int) m, (int) n, (int) n_pad, nb, \
-                           n_tok_tiles, total, per_xcd); }
+        I8Mats im; int rbs = 0;                                                                                                    \
+        for (int i = 0; i < 4; ++i) {                                                                                              \
+            const int j = i < n_mats ? i : 0;                                                                                      \
+            im.w[i] = (const uint8_t *) mt[j].w; im.w_stride[i] = mt[j].w_stride; im.y[i] = mt[j].y; im.y_stride[i] = mt[j].y_stride; im.m[i] = (int) mt[j].m; \
+            im.rb_begin[i] = i < n_mats ? rbs : 0x7FFFFFFF;                                                                        \
+            if (i < n_mats) rbs += (int) ((mt[i].m + bm - 1) / bm);                                                                \
+        }                                                                                                                          \
+        const int n_tok_tiles = (int) (n_pad / bn), total = rbs * n_tok_tiles, per_xcd = (total + 7) / 8;                         \
+        if (total > 0)                                                                                                             \
+            hipLaunchKernelGGL((k_mmq_i8_q4k<RT, TT, STAMPS>), dim3((unsigned) (8 * per_xcd)), dim3(256), lds_bytes, stream, im,    \
+                               (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, (int) n, (int) n_pad, nb, n_tok_tiles, total, per_xcd); }
     static const bool stamps = getenv("MI355Q_I8_STAMPS") != nullptr;       // dev: phase times of workgroup 0 into y[0][0..3] (tools/pp_shape.py)
     static const int force = getenv("MI355Q_I8_CFG") ? atoi(getenv("MI355Q_I8_CFG")) : 0;      // dev: 28 / 24 / 18 / 14 = RT, TT
     const int cfg = force ? force : (wide ? 28 : 14);
@@ -287,6 +308,13 @@ int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, i
     else MI355Q_I8_LAUNCH(1, 4, false)
 #undef MI355Q_I8_LAUNCH
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
+}
+
+int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
+                  float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare) {
+    if (m <= 0) return mmq_i8_supported(type, k) ? MI355Q_OK : MI355Q_ERR_UNSUPPORTED;
+    const mi355q_mat mt = { type, w, w_stride, y, y_stride, m };
+    return launch_mmq_i8_multi(&mt, 1, x, x_stride, n, k, workspace, n_cu, stream, prepare);
 }
 
 } // namespace mi355q
