@@ -23,7 +23,8 @@ int launch_pack(int type, void * dst, const void * src, int64_t nrows, int64_t k
 bool mmq_supported(int type, int64_t k);
 size_t mmq_workspace(int64_t n, int64_t k);
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                    int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare);
+                    int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare);
+size_t mmq_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu);
 bool mmq_i8_supported(int type, int64_t k);
 int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
                   int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare);
@@ -208,10 +209,10 @@ int mi355q_quantize_act(int act_type, const float * x, int64_t x_stride_bytes, v
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t) 255; }
 
 size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k) {
-    (void) m;
     const TypeInfo * t = type_info(type);
     if (!t || t->act < 0 || k % t->blck) return 0;
-    if (is_planar(t, k)) return mmq_supported(type, k) ? mmq_workspace(n, k) : 0;   // GEMV tier: fused prologue, no scratch; MFMA tier: bf16 activations
+    // GEMV tier: fused prologue, no scratch; matrix-core tiers: the prepared activations (+ split-K partial sums for shapes that are cut along K)
+    if (is_planar(t, k)) return mmq_supported(type, k) && n > 8 ? mmq_workspace(n, k) + (mmq_i8_supported(type, k) ? 0 : mmq_split_workspace(m, n, k, cu_count())) : (mmq_supported(type, k) ? mmq_workspace(n, k) : 0);
     return (size_t) align256(mi355q_row_size(t->act, k) * n);
 }
 
@@ -261,7 +262,7 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
             bool first = true;
             for (int i = 0; i < n_mats; ++i)
                 if (!(i8_ok && mmq_i8_supported(mats[i].type, k))) {
-                    MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, cu_count(), st, first));
+                    MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, workspace_bytes, cu_count(), st, first));
                     first = false;
                 }
             return MI355Q_OK;

@@ -193,7 +193,7 @@ template <> struct W32<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]
 template <int T, int MMQ_BM, int MMQ_BN>
 __global__ void __launch_bounds__(MMQ_THREADS, (MMQ_BM == 64 && MMQ_BN == 64) ? 4 : 2)
 k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __restrict__ xb /* bf16 [n][k] */,
-           float * __restrict__ y, int64_t y_stride, int m, int n, int k) {
+           float * __restrict__ y, int64_t y_stride, int m, int n, int k, int n_split, int64_t split_stride /* floats between the partial outputs */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t * Ws = lds;
     uint8_t * Xs = lds + MMQ_BM * MMQ_LDS_STRIDE;                          // BN rows
@@ -203,7 +203,11 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
     constexpr int UW = MMQ_BM * 4 / MMQ_THREADS, UX = MMQ_BN * 4 / MMQ_THREADS;
     const int m0 = blockIdx.x * MMQ_BM, n0 = blockIdx.y * MMQ_BN;
     const int nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
-    const int steps = k / MMQ_BK;
+    // split K (blockIdx.z): a shape whose 128 x 128 tiles do not fill the chip is cut along K instead of into smaller tiles (each weight is
+    // then dequantized for 128 tokens, not 64); piece z writes its partial sums to y + z * split_stride, k_mmq_reduce adds them in order
+    const int steps_all = k / MMQ_BK;
+    const int step_lo = (int) ((int64_t) steps_all * blockIdx.z / n_split), steps = (int) ((int64_t) steps_all * (blockIdx.z + 1) / n_split) - step_lo;
+    y += (int64_t) blockIdx.z * split_stride;
 
     // dequant units: (row, quarter) = ((tid + 256 u) >> 2, tid & 3), u < UW; out-of-range rows read row 0 (never stored).
     // (Named variables, not arrays indexed by u: the compiler leaves such small arrays in scratch memory.)
@@ -238,7 +242,7 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
         *(uint4 *) (dst)      = make_uint4(b0, b1, b2, b3);   *(uint4 *) (dst + 16) = make_uint4(b4, b5, b6, b7);
         *(uint4 *) (dst + 32) = make_uint4(b8, b9, b10, b11); *(uint4 *) (dst + 48) = make_uint4(b12, b13, b14, b15);
     };
-    fetch(0);
+    fetch(step_lo);
 
     for (int ks = 0; ks < steps; ++ks) {
         // ---- stage step ks into LDS (registers were loaded one step ahead) ----
@@ -254,7 +258,7 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
         }
         __syncthreads();
         // ---- prefetch step ks+1 while the matrix cores work on step ks (the last step re-reads itself: no branch) ----
-        fetch(ks + 1 < steps ? ks + 1 : ks);
+        fetch(step_lo + (ks + 1 < steps ? ks + 1 : ks));
         // ---- 4 k-slices of 32: A = W rows (lane: row l&15, k 8*(l>>4)..+7), B = tokens (lane: col l&15, same k) ----
 #pragma unroll
         for (int kk = 0; kk < MMQ_BK / 32; ++kk) {
@@ -290,6 +294,16 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
     }
 }
 
+// y[i] = part[0][i] + part[1][i] + ... (fixed order: deterministic)
+__global__ void __launch_bounds__(256) k_mmq_reduce(const float * __restrict__ part, int n_split, int64_t split_stride, float * __restrict__ y, int64_t y_stride, int64_t m, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n * (m / 4); i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t r = i / (m / 4), c = i - r * (m / 4);
+        f32x4 a = *(const f32x4 *) (part + r * m + 4 * c);
+        for (int z = 1; z < n_split; ++z) a += *(const f32x4 *) (part + z * split_stride + r * m + 4 * c);
+        *(f32x4 *) ((char *) y + r * y_stride + 16 * c) = a;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 bool mmq_supported(int type, int64_t k) {
     switch (type) {
@@ -304,11 +318,25 @@ size_t mmq_workspace(int64_t n, int64_t k) {                  // one scratch siz
     const size_t a = (size_t) (n * k * 2 + 255) & ~(size_t) 255, b = k % 256 == 0 ? mmq_i8_workspace(n, k) : 0;
     return a > b ? a : b;
 }
+// extra scratch behind mmq_workspace for split-K partial sums of an m-row matrix (0 when the shape is not split)
+static int mmq_bf16_splits(int64_t m, int64_t n, int64_t k, int n_cu) {
+    const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
+    if (2 * t128 >= 3 * (int64_t) n_cu || k < 4096 || m % 4) return 1;      // fills the chip as it is / too little K to cut
+    int s = (int) ((2 * (int64_t) n_cu + t128 - 1) / t128);                    // aim at two workgroups per CU
+    const int max_s = (int) (k / MMQ_BK / 8);                                  // at least 8 steps per piece
+    if (s > max_s) s = max_s;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
+size_t mmq_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu) {
+    const int s = mmq_bf16_splits(m, n, k, n_cu);
+    return s > 1 ? (size_t) s * (size_t) n * (size_t) m * 4 + 256 : 0;
+}
 
 // w: planar device rows; x f32 [n][k] (row stride x_stride); workspace >= mmq_workspace(n,k); y f32 [n][m] (y_stride % 16 == 0)
 // `prepare` = convert the activations to bf16 first (matrices multiplied with the same activations share the copy)
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare) {
+                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare) {
     if (!mmq_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (m <= 0 || n <= 0) return MI355Q_OK;
     if ((y_stride & 15) || ((uintptr_t) y & 15)) return MI355Q_ERR_ALIGN;
@@ -322,7 +350,13 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     int bm = 64, bn = 64;                                     // measured on pp512 shapes: 128x128 wins from ~1.5 workgroups per CU on
     if (2 * tiles(128, 128) >= 3 * (int64_t) n_cu) { bm = 128; bn = 128; }
     else if (tiles(128, 64) >= 2 * (int64_t) n_cu) { bm = 128; bn = 64; }
-    const dim3 grid((unsigned) ((m + bm - 1) / bm), (unsigned) ((n + bn - 1) / bn));
+    // ... or 128 x 128 tiles on K pieces (partial sums behind the activation copy in the scratch buffer, added up by k_mmq_reduce)
+    int splits = mmq_bf16_splits(m, n, k, n_cu);
+    const size_t part_off = mmq_workspace(n, k);
+    if (splits > 1 && workspace_bytes < part_off + (size_t) splits * (size_t) n * (size_t) m * 4) splits = 1;
+    float * yk = y; int64_t yk_stride = y_stride; int64_t split_stride = 0;
+    if (splits > 1) { bm = 128; bn = 128; yk = (float *) ((char *) workspace + part_off); yk_stride = 4 * m; split_stride = n * m; }
+    const dim3 grid((unsigned) ((m + bm - 1) / bm), (unsigned) ((n + bn - 1) / bn), (unsigned) splits);
 #define MI355Q_MMQ_LAUNCH(T, BM, BN) {                                                                                             \
         constexpr size_t lds_bytes = (size_t) (BM + BN) * MMQ_LDS_STRIDE;          /* 68 / 51 / 34 KiB */                           \
         static bool attr_set[64] = {};          /* the attribute is per device: the plugin drives every visible GPU from one process */ \
@@ -333,7 +367,7 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
             attr_set[dev_] = true;                                                                                                 \
         }                                                                                                                          \
         hipLaunchKernelGGL((k_mmq_bf16<T, BM, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,     \
-                           (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k); }
+                           (const uint16_t *) workspace, yk, yk_stride, (int) m, (int) n, (int) k, splits, split_stride); }
 #define MI355Q_MMQ_CASE(T) case T: if (bm == 128 && bn == 128) MI355Q_MMQ_LAUNCH(T, 128, 128) else if (bm == 128) MI355Q_MMQ_LAUNCH(T, 128, 64) else MI355Q_MMQ_LAUNCH(T, 64, 64) break;
     switch (type) {
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q5_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q6_K)
@@ -342,6 +376,11 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     }
 #undef MI355Q_MMQ_CASE
 #undef MI355Q_MMQ_LAUNCH
+    if (splits > 1) {
+        const int64_t quads = n * (m / 4);
+        hipLaunchKernelGGL(k_mmq_reduce, dim3((unsigned) ((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096)), dim3(256), 0, stream,
+                           (const float *) yk, splits, split_stride, y, y_stride, m, n);
+    }
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
 }
 
