@@ -26,10 +26,9 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
                     int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare);
 size_t mmq_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu);
 bool mmq_i8_supported(int type, int64_t k);
-int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                  int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare);
 int launch_mmq_i8_multi(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
-                        void * workspace, int n_cu, hipStream_t stream, bool prepare);
+                        void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare);
+size_t mmq_i8_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu);
 
 // tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
 static bool use_mmq(int type, int64_t n, int64_t k, int flags) {
@@ -212,7 +211,7 @@ size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k) {
     const TypeInfo * t = type_info(type);
     if (!t || t->act < 0 || k % t->blck) return 0;
     // GEMV tier: fused prologue, no scratch; matrix-core tiers: the prepared activations (+ split-K partial sums for shapes that are cut along K)
-    if (is_planar(t, k)) return mmq_supported(type, k) && n > 8 ? mmq_workspace(n, k) + (mmq_i8_supported(type, k) ? 0 : mmq_split_workspace(m, n, k, cu_count())) : (mmq_supported(type, k) ? mmq_workspace(n, k) : 0);
+    if (is_planar(t, k)) return mmq_supported(type, k) && n > 8 ? mmq_workspace(n, k) + (mmq_i8_supported(type, k) ? mmq_i8_split_workspace(m, n, k, cu_count()) : mmq_split_workspace(m, n, k, cu_count())) : (mmq_supported(type, k) ? mmq_workspace(n, k) : 0);
     return (size_t) align256(mi355q_row_size(t->act, k) * n);
 }
 
@@ -258,7 +257,7 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
             const bool i8_ok = !no_i8 && !(((uintptr_t) x | (uintptr_t) x_stride) & 15);
             mi355q_mat i8m[4]; int n_i8 = 0;                 // ... and ONE grid: their row blocks are concatenated
             for (int i = 0; i < n_mats; ++i) if (i8_ok && mmq_i8_supported(mats[i].type, k) && mats[i].m > 0) i8m[n_i8++] = mats[i];
-            if (n_i8 > 0) MQ_TRY(launch_mmq_i8_multi(i8m, n_i8, x, x_stride, n, k, workspace, cu_count(), st, true));
+            if (n_i8 > 0) MQ_TRY(launch_mmq_i8_multi(i8m, n_i8, x, x_stride, n, k, workspace, workspace_bytes, cu_count(), st, true));
             bool first = true;
             for (int i = 0; i < n_mats; ++i)
                 if (!(i8_ok && mmq_i8_supported(mats[i].type, k))) {

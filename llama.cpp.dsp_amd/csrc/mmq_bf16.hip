@@ -304,6 +304,11 @@ __global__ void __launch_bounds__(256) k_mmq_reduce(const float * __restrict__ p
     }
 }
 
+void launch_mmq_reduce(const float * part, int n_split, int64_t split_stride, float * y, int64_t y_stride, int64_t m, int64_t n, hipStream_t stream) {
+    const int64_t quads = n * (m / 4);
+    hipLaunchKernelGGL(k_mmq_reduce, dim3((unsigned) ((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096)), dim3(256), 0, stream, part, n_split, split_stride, y, y_stride, m, n);
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 bool mmq_supported(int type, int64_t k) {
     switch (type) {
@@ -377,9 +382,7 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
 #undef MI355Q_MMQ_CASE
 #undef MI355Q_MMQ_LAUNCH
     if (splits > 1) {
-        const int64_t quads = n * (m / 4);
-        hipLaunchKernelGGL(k_mmq_reduce, dim3((unsigned) ((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096)), dim3(256), 0, stream,
-                           (const float *) yk, splits, split_stride, y, y_stride, m, n);
+        launch_mmq_reduce(yk, splits, split_stride, y, y_stride, m, n, stream);
     }
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
 }

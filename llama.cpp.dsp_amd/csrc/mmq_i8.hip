@@ -82,7 +82,7 @@ struct I8Mats { const uint8_t * w[4]; int64_t w_stride[4]; float * y[4]; int64_t
 template <int RT, int TT, bool STAMPS>
 __global__ void __launch_bounds__(256, 2)
 k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t * __restrict__ xs, const float * __restrict__ xd,
-             int n, int n_pad, int nb, int n_tok_tiles, int total_tiles, int per_xcd) {
+             int n, int n_pad, int nb, int n_tok_tiles, int total_tiles, int per_xcd, int n_split, int64_t split_stride) {
     constexpr int BN = 16 * TT, BM = 64 * RT;
     constexpr int XQ_BYTES = BN * I8Q_REC, XS_BYTES = BN * I8Q_XS, XD_BYTES = BN * 4, BUF = XQ_BYTES + XS_BYTES + XD_BYTES;
     constexpr int XQ_PIECES = XQ_BYTES / 1024, XS_PIECES = XS_BYTES / 1024;          // 1 KiB per wave-instruction (64 lanes x 16 B)
@@ -143,13 +143,15 @@ k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t *
         if (wave == 3 && 16 * lane < BN * 4) __builtin_amdgcn_global_load_lds(gd + 16 * lane, (i8q_lds_ptr) (dst + XQ_BYTES + XS_BYTES), 16, 0, 0);
     };
 
-    fetch_w(0);
-    dma_x(0, 0);
+    // split K (blockIdx.y, single-matrix launches): piece z covers super-blocks [b_lo, b_hi) and writes partial sums to y + z * split_stride
+    const int b_lo = (int) ((int64_t) nb * blockIdx.y / n_split), b_hi = (int) ((int64_t) nb * (blockIdx.y + 1) / n_split);
+    fetch_w(b_lo);
+    dma_x(b_lo, 0);
 
     [[maybe_unused]] uint64_t st_wait = 0, st_deq = 0, st_tiles = 0, st_t0 = 0, st_t1 = 0, st_t2 = 0;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = b_lo; b < b_hi; ++b) {
         if constexpr (STAMPS) st_t0 = __builtin_amdgcn_s_memrealtime();
-        const int buf = b & 1;
+        const int buf = (b - b_lo) & 1;
         // everything this wave issued (its share of tile b, its packed weights of block b) has landed; after the barrier so has every
         // other wave's share, and nobody still reads the other buffer
         __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0); expcnt / lgkmcnt untouched
@@ -188,7 +190,7 @@ k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t *
             mfrag[rt] = __builtin_bit_cast(i8q_bf16x8, fm);
         }
         // ---- prefetch block b+1 (weights into the registers just consumed, activations into the other LDS buffer) ----
-        if (b + 1 < nb) { fetch_w(b + 1); dma_x(b + 1, buf ^ 1); }
+        if (b + 1 < b_hi) { fetch_w(b + 1); dma_x(b + 1, buf ^ 1); }
         __builtin_amdgcn_sched_barrier(0);                      // keep the phases apart: the scheduler otherwise mixes them into a slower order
 
         if constexpr (STAMPS) { st_t2 = __builtin_amdgcn_s_memrealtime(); st_deq += st_t2 - st_t1; }
@@ -236,7 +238,7 @@ k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t *
     for (int rt = 0; rt < RT; ++rt) {
         const int row = m0 + 16 * rt + l16;
         if (row >= m) continue;
-        char * yp = (char *) y + (int64_t) (n0 + 4 * kq) * y_stride + 4 * (int64_t) row;
+        char * yp = (char *) (y + (int64_t) blockIdx.y * split_stride) + (int64_t) (n0 + 4 * kq) * y_stride + 4 * (int64_t) row;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
 #pragma unroll
@@ -262,8 +264,25 @@ size_t mmq_i8_workspace(int64_t n, int64_t k) {
 // w: planar device rows; x f32 [n][k] (row stride x_stride, 16-byte aligned rows); workspace >= mmq_i8_workspace(n,k); y f32 [n][m]
 // One grid for up to 4 Q4_K matrices on the same activations.  w: planar device rows; x f32 [n][k] (16-byte aligned rows);
 // workspace >= mmq_i8_workspace(n,k); y_i f32 [n][m_i].  prepare: write the activation image first.
+void launch_mmq_reduce(const float * part, int n_split, int64_t split_stride, float * y, int64_t y_stride, int64_t m, int64_t n, hipStream_t stream);
+
+// K pieces for a single matrix whose 128 x 128 tiles do not fill the chip (as the bf16 tier does): 0/1 = no split
+static int mmq_i8_splits(int64_t m, int64_t n, int64_t k, int n_cu) {
+    const int64_t t128 = ((m + 127) / 128) * (i8q_npad(n) / 128);
+    if (2 * t128 >= 3 * (int64_t) n_cu || k < 8192 || m % 4) return 1;           // (K = 4096: measured no gain over 64 x 64 tiles)
+    int s = (int) ((2 * (int64_t) n_cu + t128 - 1) / t128);
+    const int max_s = (int) (k / 256 / 4);                                     // at least 4 super-blocks per piece
+    if (s > max_s) s = max_s;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
+size_t mmq_i8_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu) {
+    const int s = mmq_i8_splits(m, n, k, n_cu);
+    return s > 1 ? (size_t) s * (size_t) n * (size_t) m * 4 + 256 : 0;
+}
+
 int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
-                        void * workspace, int n_cu, hipStream_t stream, bool prepare) {
+                        void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare) {
     if (n_mats < 1 || n_mats > 4) return MI355Q_ERR_SHAPE;
     for (int i = 0; i < n_mats; ++i) if (!mmq_i8_supported(mt[i].type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (n <= 0) return MI355Q_OK;
@@ -277,7 +296,15 @@ int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int6
     // 128 rows x 128 tokens per workgroup (the dequantization is shared by most tokens) when that still gives a CU 1.5 workgroups;
     // otherwise 64 x 64 (four times the workgroups, 3-4 per CU): measured at N = 512, 4096 x 4096: 47 -> 42 us, 4096 x 14336: 147 -> 128 us
     int64_t rb128 = 0; for (int i = 0; i < n_mats; ++i) rb128 += (mt[i].m + 127) / 128;
-    const bool wide = 2 * rb128 * (n_pad / 128) >= 3 * (int64_t) n_cu;
+    // ... or, for a single matrix, 128 x 128 tiles over K pieces (partial sums behind the activation image, added up by k_mmq_reduce)
+    int splits = n_mats == 1 ? mmq_i8_splits(mt[0].m, n, k, n_cu) : 1;
+    const size_t part_off = mmq_i8_workspace(n, k);
+    if (splits > 1 && (workspace_bytes < part_off + (size_t) splits * (size_t) n * (size_t) mt[0].m * 4 || (mt[0].y_stride & 15) || ((uintptr_t) mt[0].y & 15))) splits = 1;
+    mi355q_mat part_mat;
+    if (splits > 1) { part_mat = mt[0]; part_mat.y = (float *) ((char *) workspace + part_off); part_mat.y_stride = 4 * mt[0].m; }
+    const mi355q_mat * src = splits > 1 ? &part_mat : mt;
+    const int64_t split_stride = splits > 1 ? n * mt[0].m : 0;
+    const bool wide = splits > 1 || 2 * rb128 * (n_pad / 128) >= 3 * (int64_t) n_cu;
 #define MI355Q_I8_LAUNCH(RT, TT, STAMPS) {                                                                                         \
         constexpr int bn = 16 * TT, bm = 64 * RT;                                                                                  \
         const size_t lds_bytes = 2 * (size_t) (bn * (I8Q_REC + I8Q_XS + 4));                                                       \
@@ -291,14 +318,14 @@ int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int6
         I8Mats im; int rbs = 0;                                                                                                    \
         for (int i = 0; i < 4; ++i) {                                                                                              \
             const int j = i < n_mats ? i : 0;                                                                                      \
-            im.w[i] = (const uint8_t *) mt[j].w; im.w_stride[i] = mt[j].w_stride; im.y[i] = mt[j].y; im.y_stride[i] = mt[j].y_stride; im.m[i] = (int) mt[j].m; \
+            im.w[i] = (const uint8_t *) src[j].w; im.w_stride[i] = src[j].w_stride; im.y[i] = src[j].y; im.y_stride[i] = src[j].y_stride; im.m[i] = (int) src[j].m; \
             im.rb_begin[i] = i < n_mats ? rbs : 0x7FFFFFFF;                                                                        \
             if (i < n_mats) rbs += (int) ((mt[i].m + bm - 1) / bm);                                                                \
         }                                                                                                                          \
         const int n_tok_tiles = (int) (n_pad / bn), total = rbs * n_tok_tiles, per_xcd = (total + 7) / 8;                         \
         if (total > 0)                                                                                                             \
-            hipLaunchKernelGGL((k_mmq_i8_q4k<RT, TT, STAMPS>), dim3((unsigned) (8 * per_xcd)), dim3(256), lds_bytes, stream, im,    \
-                               (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, (int) n, (int) n_pad, nb, n_tok_tiles, total, per_xcd); }
+            hipLaunchKernelGGL((k_mmq_i8_q4k<RT, TT, STAMPS>), dim3((unsigned) (8 * per_xcd), (unsigned) splits), dim3(256), lds_bytes, stream, im, \
+                               (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, (int) n, (int) n_pad, nb, n_tok_tiles, total, per_xcd, splits, split_stride); }
     static const bool stamps = getenv("MI355Q_I8_STAMPS") != nullptr;       // dev: phase times of workgroup 0 into y[0][0..3] (tools/pp_shape.py)
     static const int force = getenv("MI355Q_I8_CFG") ? atoi(getenv("MI355Q_I8_CFG")) : 0;      // dev: 28 / 24 / 18 / 14 = RT, TT
     const int cfg = force ? force : (wide ? 28 : 14);
@@ -307,14 +334,15 @@ int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int6
     else if (cfg == 18) MI355Q_I8_LAUNCH(1, 8, false)
     else MI355Q_I8_LAUNCH(1, 4, false)
 #undef MI355Q_I8_LAUNCH
+    if (splits > 1) launch_mmq_reduce(part_mat.y, splits, split_stride, mt[0].y, mt[0].y_stride, mt[0].m, n, stream);
     return hipGetLastError() == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
 }
 
 int launch_mmq_i8(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                  float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, int n_cu, hipStream_t stream, bool prepare) {
+                  float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare) {
     if (m <= 0) return mmq_i8_supported(type, k) ? MI355Q_OK : MI355Q_ERR_UNSUPPORTED;
     const mi355q_mat mt = { type, w, w_stride, y, y_stride, m };
-    return launch_mmq_i8_multi(&mt, 1, x, x_stride, n, k, workspace, n_cu, stream, prepare);
+    return launch_mmq_i8_multi(&mt, 1, x, x_stride, n, k, workspace, workspace_bytes, n_cu, stream, prepare);
 }
 
 } // namespace mi355q

@@ -309,7 +309,10 @@ def test_multi_equals_single(G, torch, orc):
         multi = [y.cpu().numpy() for y in G.mul_mat_multi(ws, x)]
         for (t, m), h, w, ym in zip(specs, hosts, ws, multi):
             single = G.mul_mat(w, x).cpu().numpy()
-            assert np.array_equal(single.view(np.uint32), ym.view(np.uint32))
+            if N <= 8:
+                assert np.array_equal(single.view(np.uint32), ym.view(np.uint32))          # the decode contract: bit-identical
+            else:
+                check_close(ym, single, "multi vs single")        # (a single matrix may be cut along K: another f32 summation order)
             check(G, t, K, N, ym, orc.mul_mat(t, h, x.cpu().numpy(), m, N, K), f"multi N={N}")
 
 
