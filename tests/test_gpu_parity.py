@@ -374,6 +374,36 @@ def test_full_size_sampled_rows_and_properties(G, torch, orc, t, M, K):
     assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))
 
 
+@pytest.mark.parametrize("t,M,K", [(oracle.Q4_K, 14336, 4096), (oracle.Q4_K, 4096, 14336), (oracle.Q6_K, 4096, 14336), (oracle.Q6_K, 1024, 4096)],
+                         ids=lambda v: str(v))
+def test_full_size_prefill_sampled_and_properties(G, torch, orc, t, M, K):
+    """pp512 at the BASELINE.json sizes (the integer tier with 128x128 tiles, its split-K form, the bf16 tier's split-K form): sampled
+    rows / tokens against the oracle, and size-independent properties -- determinism across launches, token rows independent of the other
+    tokens of the batch (a token computed in a batch of 512 equals the same token in a batch of 140, up to the f32 summation order where
+    the tile shape changes), row permutations of W permute the outputs."""
+    N = 512
+    rng = np.random.default_rng(M + K + t + 5)
+    w = random_blocks(t, M, K, rng)
+    wq = G.QWeight.from_host(t, w, M, K)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    y = G.mul_mat(wq, xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    rows = np.unique(np.concatenate([[0, M - 1], rng.integers(0, M, 30)])); toks = np.unique(np.concatenate([[0, N - 1], rng.integers(0, N, 6)]))
+    ref = orc.mul_mat(t, w[rows], x[toks], len(rows), len(toks), K)
+    if t == oracle.Q4_K:
+        check_close(y[np.ix_(toks, rows)], ref, f"{ids_t(t)} {M}x{K} N={N}")          # the CPU arithmetic on the integer tier
+    else:
+        assert nmse(y[np.ix_(toks, rows)], ref) <= 5e-4
+    y2 = G.mul_mat(wq, xd).cpu().numpy()
+    assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))                       # deterministic (split-K partial sums are added in fixed order)
+    ys = G.mul_mat(wq, xd[:140]).cpu().numpy()                                         # another batch size: other tiles / pieces, same numbers
+    assert np.abs(ys - y[:140]).max() <= 2e-5 * np.abs(y).max()
+    perm = rng.permutation(M)
+    yp = G.mul_mat(G.QWeight.from_host(t, w[perm], M, K), xd).cpu().numpy()
+    assert np.abs(yp - y[:, perm]).max() <= 2e-5 * np.abs(y).max()
+
+
 def test_output_layer_rows(G, torch, orc):
     """The 128256 x 4096 Q6_K output matrix of Llama-3-8B Q4_K_M: maximum row count of the workload."""
     t, M, K = oracle.Q6_K, 128256, 4096
