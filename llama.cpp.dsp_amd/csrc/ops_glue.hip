@@ -467,6 +467,73 @@ __global__ void __launch_bounds__(256) k_flash_attn_combine(const float * __rest
 }
 
 
+// ---- the same product for many src1 rows (prefill attention: KQ and KQV of a 512-token batch) on the matrix cores -------------------
+// dst[n][m] = sum_k a[m][k] * f16(b[n][k]),  a f16.  64 x 64 output tile per workgroup (2 x 2 waves of 2 x 2 v_mfma_f32_16x16x32_f16), K in
+// steps of 64 through LDS (a copied as it is, b rounded to f16 on the way in, rows padded by 16 B against bank conflicts).  Products of two
+// f16 numbers are exact in f32 and the accumulation is f32, as in the CPU's f16 dot product; only the summation order differs.
+typedef _Float16 mmf_h8 __attribute__((ext_vector_type(8)));
+typedef float    mmf_f4 __attribute__((ext_vector_type(4)));
+constexpr int MMF_T = 64, MMF_K = 64, MMF_LDS_ROW = MMF_K * 2 + 16;
+__global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const TensorD b, const TensorD d) {
+    __shared__ __attribute__((aligned(16))) uint8_t As[MMF_T * MMF_LDS_ROW], Bs[MMF_T * MMF_LDS_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int64_t M = d.ne[0], N = d.ne[1], K = a.ne[0];
+    const int64_t m0 = (int64_t) blockIdx.x * MMF_T, n0 = (int64_t) blockIdx.y * MMF_T;
+    const int64_t i12 = blockIdx.z % d.ne[2], i13 = blockIdx.z / d.ne[2];
+    const int64_t i02 = i12 / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
+    const int row = tid >> 2, seg = tid & 3;                                  // staging: thread -> (tile row, 16-element k segment)
+    const int64_t am = m0 + row < M ? m0 + row : M - 1, bn = n0 + row < N ? n0 + row : N - 1;
+    const char * ap = a.data + am * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3];
+    const char * bp = b.data + bn * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3];
+    mmf_f4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (mmf_f4) { 0.f, 0.f, 0.f, 0.f };
+    for (int64_t k0 = 0; k0 < K; k0 += MMF_K) {
+        const int64_t ks = k0 + 16 * seg;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0, f3 = f0;
+        if (ks < K) {                                                         // K is a multiple of 16 (checked by the launcher)
+            a0 = *(const uint4 *) (ap + 2 * ks); a1 = *(const uint4 *) (ap + 2 * ks + 16);
+            const float4 * bq = (const float4 *) (bp + 4 * ks);
+            f0 = bq[0]; f1 = bq[1]; f2 = bq[2]; f3 = bq[3];
+        }
+        __syncthreads();                                                      // the previous step's fragments have been read
+        *(uint4 *) (As + row * MMF_LDS_ROW + 32 * seg) = a0; *(uint4 *) (As + row * MMF_LDS_ROW + 32 * seg + 16) = a1;
+        const mmf_h8 h0 = { (_Float16) f0.x, (_Float16) f0.y, (_Float16) f0.z, (_Float16) f0.w, (_Float16) f1.x, (_Float16) f1.y, (_Float16) f1.z, (_Float16) f1.w };
+        const mmf_h8 h1 = { (_Float16) f2.x, (_Float16) f2.y, (_Float16) f2.z, (_Float16) f2.w, (_Float16) f3.x, (_Float16) f3.y, (_Float16) f3.z, (_Float16) f3.w };
+        *(mmf_h8 *) (Bs + row * MMF_LDS_ROW + 32 * seg) = h0; *(mmf_h8 *) (Bs + row * MMF_LDS_ROW + 32 * seg + 16) = h1;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < MMF_K / 32; ++kk) {
+            const int koff = 2 * (32 * kk + 8 * (lane >> 4));
+            mmf_h8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const mmf_h8 *) (As + (32 * wm + 16 * i + (lane & 15)) * MMF_LDS_ROW + koff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *(const mmf_h8 *) (Bs + (32 * wn + 16 * j + (lane & 15)) * MMF_LDS_ROW + koff);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // C rows = src0 rows m (4 consecutive per lane), C column = src1 row n
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t n = n0 + 32 * wn + 16 * j + (lane & 15);
+        if (n >= N) continue;
+        char * dr = d.data + n * d.nb[1] + i12 * d.nb[2] + i13 * d.nb[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t m = m0 + 32 * wm + 16 * i + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (m + r < M) *(float *) (dr + (m + r) * d.nb[0]) = acc[i][j][r];
+        }
+    }
+}
+
 // ---- GET_ROWS (f32 / f16 rows -> f32): dst[:, i10, i11, i12] = src0[:, ids[i10, i11, i12], i11, i12]   ops.cpp:4272-4311 -------
 __global__ void __launch_bounds__(256) k_get_rows(const TensorD a, const char * ids, int64_t nb10, int64_t nb11, int64_t nb12,
                                                   int64_t ne10, int64_t ne11, const TensorD d, int64_t n) {
@@ -697,6 +764,13 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
     if (a->nb[0] != (a->type == 0 ? 4 : 2) || b->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: the k dimension must be contiguous in both operands");
     const int64_t n_out = nelements(dst);
     if (n_out == 0) return MI355Q_OK;
+    // many src1 rows and an f16 src0 (prefill attention): matrix cores
+    if (a->type == 1 && b->ne[1] >= 16 && dst->ne[0] >= 16 && a->ne[0] % 16 == 0 && dst->ne[2] * dst->ne[3] <= 65535 &&
+        !(((uintptr_t) a->data | (uintptr_t) a->nb[1] | (uintptr_t) a->nb[2] | (uintptr_t) a->nb[3] | (uintptr_t) b->data | (uintptr_t) b->nb[1] | (uintptr_t) b->nb[2] | (uintptr_t) b->nb[3]) & 15)) {
+        hipLaunchKernelGGL(k_mul_mat_f16_mfma, dim3((unsigned) ((dst->ne[0] + MMF_T - 1) / MMF_T), (unsigned) ((dst->ne[1] + MMF_T - 1) / MMF_T), (unsigned) (dst->ne[2] * dst->ne[3])),
+                           dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst));
+        OPS_LAUNCHED();
+    }
     const int64_t groups_per_col = (dst->ne[0] + MMF_ROWS - 1) / MMF_ROWS, n_groups = groups_per_col * dst->ne[1] * dst->ne[2] * dst->ne[3];
     if ((n_groups + 3) / 4 > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_mul_mat_f: too many outputs");
     hipLaunchKernelGGL(k_mul_mat_f, dim3((unsigned) ((n_groups + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst), n_groups, groups_per_col);

@@ -126,6 +126,23 @@ def test_mul_mat_f_attention_shapes(G, torch):
     assert np.abs(y - glue.mul_mat_f(v, p, False)).max() <= 2e-5 * np.abs(y).max()
 
 
+def test_mul_mat_f_prefill_on_matrix_cores(G, torch):
+    """The f16 attention products of a prefill batch (>= 16 src1 rows: v_mfma_f32_16x16x32_f16 tiles): KQ with a ragged window (n_kv and
+    n_tokens not multiples of the 64 x 64 tile), GQA broadcast, cache-strided views; KQV with K = n_kv not a multiple of the 64-step."""
+    rng = np.random.default_rng(16)
+    n_kv, hd, nh, nkvh, nt, n_ctx = 336, 128, 8, 2, 150, 400
+    kc = rng.standard_normal((n_ctx, nkvh * hd)).astype(np.float32)
+    k_view = dev(torch, kc).half()[:n_kv].view(n_kv, nkvh, hd).permute(1, 0, 2)[None]
+    q = rng.standard_normal((nt, nh, hd)).astype(np.float32)
+    y = G.op_mul_mat_f(k_view, dev(torch, q).permute(1, 0, 2)[None]).cpu().numpy()
+    ref = glue.mul_mat_f(kc[:n_kv].reshape(n_kv, nkvh, hd).transpose(1, 0, 2)[None], q.transpose(1, 0, 2)[None], True)
+    assert y.shape == (1, nh, nt, n_kv) and np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+    vc = rng.standard_normal((1, nkvh, hd, n_ctx)).astype(np.float32)
+    p = rng.random((1, nh, nt, n_kv)).astype(np.float32)
+    y = G.op_mul_mat_f(dev(torch, vc).half()[..., :n_kv], dev(torch, p)).cpu().numpy()
+    assert np.abs(y - glue.mul_mat_f(vc[..., :n_kv], p, True)).max() <= 2e-5 * np.abs(y).max()
+
+
 # ------------------------------------------------------------------------------------------------
 # fused forms (SURVEY.md 8f-2): bit-identical to the chain of separate ops they replace
 # ------------------------------------------------------------------------------------------------
