@@ -248,8 +248,9 @@ int mi355q_op_unary_mul(int uop, const mi355q_tensor *a, const mi355q_tensor *b,
  *   q f32 [DK, N, H, B], k f16 [DK, n_kv, Hk, Bk], v f16 [DV, n_kv, Hv, Bv] (NOT transposed), mask f16 [>= n_kv, >= N] or NULL,
  *   dst f32 [DV, H, N, B];  dst = softmax(softcap(scale k.q) + slope_h mask) v,  head sizes <= 256, n_kv <= 36864.
  * workspace (optional, mi355q_op_flash_attn_ext_workspace bytes): with it, a call with few query rows (decode) splits the KV range over
- * several workgroups per row and merges the pieces in a second launch; without it every row is one workgroup.                     */
-size_t mi355q_op_flash_attn_ext_workspace(int64_t dv, int64_t n_q, int64_t n_head, int64_t n_batch);
+ * several workgroups per row and merges the pieces in a second launch, and a call with >= 16 query rows (prefill) computes scores,
+ * softmax and P V on the matrix-core kernels with the scores of the batch in the workspace; without it every row is one workgroup.   */
+size_t mi355q_op_flash_attn_ext_workspace(int64_t dv, int64_t n_q, int64_t n_head, int64_t n_batch, int64_t n_kv);
 int mi355q_op_flash_attn_ext(const mi355q_tensor *q, const mi355q_tensor *k, const mi355q_tensor *v, const mi355q_tensor *mask,
                              const mi355q_tensor *dst, float scale, float max_bias, float logit_softcap,
                              void *workspace, size_t workspace_bytes, void *stream);

@@ -343,7 +343,7 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int
         memcpy(&softcap, (const float *) dst->op_params + 2, sizeof(float));
         const mi355q_tensor k = mi355_td(dst->src[1]), v = mi355_td(dst->src[2]);
         mi355q_tensor m; if (dst->src[3]) m = mi355_td(dst->src[3]);
-        const size_t ws = mi355q_op_flash_attn_ext_workspace(v.ne[0], a.ne[1], a.ne[2], a.ne[3]);
+        const size_t ws = mi355q_op_flash_attn_ext_workspace(v.ne[0], a.ne[1], a.ne[2], a.ne[3], k.ne[1]);
         void * wsp = mi355_workspace(ctx, ws);
         MQ_CHECK(mi355q_op_flash_attn_ext(&a, &k, &v, dst->src[3] ? &m : nullptr, &d, scale, max_bias, softcap, wsp, ws, ctx->stream));
     } break;

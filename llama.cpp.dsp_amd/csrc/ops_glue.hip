@@ -474,6 +474,9 @@ __global__ void __launch_bounds__(256) k_flash_attn_combine(const float * __rest
 typedef _Float16 mmf_h8 __attribute__((ext_vector_type(8)));
 typedef float    mmf_f4 __attribute__((ext_vector_type(4)));
 constexpr int MMF_T = 64, MMF_K = 64, MMF_LDS_ROW = MMF_K * 2 + 16;
+// AT: src0 is given TRANSPOSED in memory -- a.data[k][m] with m contiguous (a.nb[1] = bytes between consecutive k): the V cache of the
+// flash-attention layout, one row per position, read for out[n][m] = sum_k p[n][k] v[k][m].  a.ne still reads [K, M, ..].
+template <bool AT>
 __global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const TensorD b, const TensorD d) {
     __shared__ __attribute__((aligned(16))) uint8_t As[MMF_T * MMF_LDS_ROW], Bs[MMF_T * MMF_LDS_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -483,7 +486,7 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const
     const int64_t i02 = i12 / (b.ne[2] / a.ne[2]), i03 = i13 / (b.ne[3] / a.ne[3]);
     const int row = tid >> 2, seg = tid & 3;                                  // staging: thread -> (tile row, 16-element k segment)
     const int64_t am = m0 + row < M ? m0 + row : M - 1, bn = n0 + row < N ? n0 + row : N - 1;
-    const char * ap = a.data + am * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3];
+    const char * ap = AT ? a.data + i02 * a.nb[2] + i03 * a.nb[3] : a.data + am * a.nb[1] + i02 * a.nb[2] + i03 * a.nb[3];
     const char * bp = b.data + bn * b.nb[1] + i12 * b.nb[2] + i13 * b.nb[3];
     mmf_f4 acc[2][2];
 #pragma unroll
@@ -495,12 +498,27 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
         float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0, f3 = f0;
         if (ks < K) {                                                         // K is a multiple of 16 (checked by the launcher)
-            a0 = *(const uint4 *) (ap + 2 * ks); a1 = *(const uint4 *) (ap + 2 * ks + 16);
+            if constexpr (!AT) { a0 = *(const uint4 *) (ap + 2 * ks); a1 = *(const uint4 *) (ap + 2 * ks + 16); }
             const float4 * bq = (const float4 *) (bp + 4 * ks);
             f0 = bq[0]; f1 = bq[1]; f2 = bq[2]; f3 = bq[3];
         }
+        if constexpr (AT) {                                                   // thread -> (k = k0 + row, 16 consecutive m): transposed on the way into LDS
+            if (k0 + row < K && m0 + 16 * seg < M) {                          // (M is a multiple of 16: checked by the launcher)
+                const char * vp = ap + (k0 + row) * a.nb[1] + 2 * (m0 + 16 * seg);
+                a0 = *(const uint4 *) vp; a1 = *(const uint4 *) (vp + 16);
+            }
+        }
         __syncthreads();                                                      // the previous step's fragments have been read
-        *(uint4 *) (As + row * MMF_LDS_ROW + 32 * seg) = a0; *(uint4 *) (As + row * MMF_LDS_ROW + 32 * seg + 16) = a1;
+        if constexpr (AT) {
+            const uint32_t wv[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                *(uint16_t *) (As + (16 * seg + 2 * i) * MMF_LDS_ROW + 2 * row)     = (uint16_t) (wv[i] & 0xFFFFu);
+                *(uint16_t *) (As + (16 * seg + 2 * i + 1) * MMF_LDS_ROW + 2 * row) = (uint16_t) (wv[i] >> 16);
+            }
+        } else {
+            *(uint4 *) (As + row * MMF_LDS_ROW + 32 * seg) = a0; *(uint4 *) (As + row * MMF_LDS_ROW + 32 * seg + 16) = a1;
+        }
         const mmf_h8 h0 = { (_Float16) f0.x, (_Float16) f0.y, (_Float16) f0.z, (_Float16) f0.w, (_Float16) f1.x, (_Float16) f1.y, (_Float16) f1.z, (_Float16) f1.w };
         const mmf_h8 h1 = { (_Float16) f2.x, (_Float16) f2.y, (_Float16) f2.z, (_Float16) f2.w, (_Float16) f3.x, (_Float16) f3.y, (_Float16) f3.z, (_Float16) f3.w };
         *(mmf_h8 *) (Bs + row * MMF_LDS_ROW + 32 * seg) = h0; *(mmf_h8 *) (Bs + row * MMF_LDS_ROW + 32 * seg + 16) = h1;
@@ -767,7 +785,7 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
     // many src1 rows and an f16 src0 (prefill attention): matrix cores
     if (a->type == 1 && b->ne[1] >= 16 && dst->ne[0] >= 16 && a->ne[0] % 16 == 0 && dst->ne[2] * dst->ne[3] <= 65535 &&
         !(((uintptr_t) a->data | (uintptr_t) a->nb[1] | (uintptr_t) a->nb[2] | (uintptr_t) a->nb[3] | (uintptr_t) b->data | (uintptr_t) b->nb[1] | (uintptr_t) b->nb[2] | (uintptr_t) b->nb[3]) & 15)) {
-        hipLaunchKernelGGL(k_mul_mat_f16_mfma, dim3((unsigned) ((dst->ne[0] + MMF_T - 1) / MMF_T), (unsigned) ((dst->ne[1] + MMF_T - 1) / MMF_T), (unsigned) (dst->ne[2] * dst->ne[3])),
+        hipLaunchKernelGGL(k_mul_mat_f16_mfma<false>, dim3((unsigned) ((dst->ne[0] + MMF_T - 1) / MMF_T), (unsigned) ((dst->ne[1] + MMF_T - 1) / MMF_T), (unsigned) (dst->ne[2] * dst->ne[3])),
                            dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(b), to_d(dst));
         OPS_LAUNCHED();
     }
@@ -777,8 +795,9 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
     OPS_LAUNCHED();
 }
 
-size_t mi355q_op_flash_attn_ext_workspace(int64_t dv, int64_t n_q, int64_t n_head, int64_t n_batch) {
-    if (n_q * n_head * n_batch > 256) return 0;                             // many rows: one workgroup per row fills the chip
+size_t mi355q_op_flash_attn_ext_workspace(int64_t dv, int64_t n_q, int64_t n_head, int64_t n_batch, int64_t n_kv) {
+    if (n_q >= 16) return (size_t) (n_q * n_kv * n_head * n_batch * 4);     // prefill: the scores of the batch
+    if (n_q * n_head * n_batch > 256) return 0;
     return (size_t) (8 * n_q * n_head * n_batch * (dv + 2) * 4);            // up to 8 pieces per row
 }
 
@@ -801,6 +820,31 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
     if (logit_softcap != 0.0f) scale /= logit_softcap;                          // ops.cpp:6757-6759
     uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= (uint32_t) n_head) n_head_log2 *= 2;
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    // Many query rows (prefill) and scratch for the scores: the three steps of the definition on the matrix-core kernels -- scores = K q
+    // (k_mul_mat_f16_mfma), row softmax with the f16 mask (k_soft_max), out = P V with V read transposed (k_mul_mat_f16_mfma<true>).  One
+    // workgroup per row (below) re-streams K and V for every row: 5x slower for a 512-token batch.
+    {
+        const size_t need = (size_t) N * (size_t) n_kv * (size_t) n_head * (size_t) nb3 * 4;
+        auto al16 = [](const mi355q_tensor * t) { return ((((uintptr_t) t->data) | (uintptr_t) t->nb[1] | (uintptr_t) t->nb[2] | (uintptr_t) t->nb[3]) & 15) == 0; };
+        if (N >= 16 && logit_softcap == 0.0f && workspace && workspace_bytes >= need && DK % 16 == 0 && DV % 16 == 0 && n_kv % 16 == 0 &&
+            al16(q) && al16(k) && al16(v) && n_head * nb3 <= 65535 && (!mask || mask->nb[1] == 2 * n_kv)) {
+            mi355q_tensor sc; sc.data = workspace; sc.type = 0;
+            sc.ne[0] = n_kv; sc.ne[1] = N; sc.ne[2] = n_head; sc.ne[3] = nb3;
+            sc.nb[0] = 4; sc.nb[1] = 4 * n_kv; sc.nb[2] = sc.nb[1] * N; sc.nb[3] = sc.nb[2] * n_head;
+            const dim3 g1((unsigned) ((n_kv + MMF_T - 1) / MMF_T), (unsigned) ((N + MMF_T - 1) / MMF_T), (unsigned) (n_head * nb3));
+            hipLaunchKernelGGL(k_mul_mat_f16_mfma<false>, g1, dim3(256), 0, (hipStream_t) stream, to_d(k), to_d(q), to_d(&sc));
+            const int rc = mi355q_op_soft_max(&sc, mask, &sc, scale, max_bias, stream);     // in place, row by row
+            if (rc != MI355Q_OK) return rc;
+            mi355q_tensor vt = *v;                             // [K = n_kv, M = DV] with M contiguous: the transposed-source form
+            vt.ne[0] = n_kv; vt.ne[1] = DV;
+            mi355q_tensor od = *dst;                           // out[n][m]: dst is [DV, H, N, B] -> rows n with stride nb[2], heads with nb[1]
+            od.ne[0] = DV; od.ne[1] = N; od.ne[2] = n_head; od.ne[3] = nb3;
+            od.nb[1] = dst->nb[2]; od.nb[2] = dst->nb[1];
+            const dim3 g2((unsigned) ((DV + MMF_T - 1) / MMF_T), (unsigned) ((N + MMF_T - 1) / MMF_T), (unsigned) (n_head * nb3));
+            hipLaunchKernelGGL(k_mul_mat_f16_mfma<true>, g2, dim3(256), 0, (hipStream_t) stream, to_d(&vt), to_d(&sc), to_d(&od));
+            OPS_LAUNCHED();
+        }
+    }
     // few rows (decode): split the KV range so that the chip is not left to n_head workgroups with long dependent chains
     int n_split = 1;
     if (N * n_head * nb3 <= 256 && n_kv >= 256) { n_split = (int) ((n_kv + 127) / 128); if (n_split > 8) n_split = 8; }

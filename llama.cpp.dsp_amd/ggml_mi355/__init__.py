@@ -131,7 +131,7 @@ def lib() -> C.CDLL:
     L.mi355q_op_add_rms_norm_mul.argtypes = [TP, TP, TP, vp, TP, C.c_float, vp]
     L.mi355q_op_unary_mul.argtypes = [i32, TP, TP, TP, vp]
     L.mi355q_op_flash_attn_ext.argtypes = [TP, TP, TP, TP, TP, C.c_float, C.c_float, C.c_float, vp, sz, vp]
-    L.mi355q_op_flash_attn_ext_workspace.restype = sz; L.mi355q_op_flash_attn_ext_workspace.argtypes = [i64, i64, i64, i64]
+    L.mi355q_op_flash_attn_ext_workspace.restype = sz; L.mi355q_op_flash_attn_ext_workspace.argtypes = [i64, i64, i64, i64, i64]
     L.mi355q_op_soft_max.argtypes = [TP, TP, TP, C.c_float, C.c_float, vp]
     L.mi355q_op_rope.argtypes = [TP, vp, vp, TP, C.POINTER(_RopeParams), vp]
     L.mi355q_op_mul_mat_f.argtypes = [TP, TP, TP, vp]
@@ -376,7 +376,7 @@ def op_flash_attn_ext(q, k, v, mask, scale: float, max_bias: float = 0.0, logit_
     or None -> f32 [B, N, H, DV]."""
     torch = _torch()
     out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), dtype=torch.float32, device=q.device)
-    ws, wsb = (_workspace(torch, int(lib().mi355q_op_flash_attn_ext_workspace(v.shape[3], q.shape[2], q.shape[1], q.shape[0])), q.device)
+    ws, wsb = (_workspace(torch, int(lib().mi355q_op_flash_attn_ext_workspace(v.shape[3], q.shape[2], q.shape[1], q.shape[0], k.shape[2])), q.device)
                if split else (None, 0))
     _check(lib().mi355q_op_flash_attn_ext(C.byref(_td(q)), C.byref(_td(k)), C.byref(_td(v)), C.byref(_td(mask)) if mask is not None else None,
                                           C.byref(_td(out)), scale, max_bias, logit_softcap, ws.data_ptr() if ws is not None else None, wsb,

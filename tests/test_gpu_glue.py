@@ -166,7 +166,8 @@ def test_fused_norm_and_activation_equal_separate_ops(G, torch):
 
 
 @pytest.mark.parametrize("cfg", [(128, 128, 8, 2, 1, 512, 0.0, 0.0), (64, 64, 4, 4, 7, 96, 0.0, 0.0), (128, 128, 8, 8, 3, 300, 8.0, 0.0),
-                                 (80, 80, 4, 1, 2, 64, 0.0, 10.0), (256, 256, 2, 2, 1, 1000, 0.0, 0.0), (128, 128, 32, 8, 1, 4096, 0.0, 0.0)], ids=str)
+                                 (80, 80, 4, 1, 2, 64, 0.0, 10.0), (256, 256, 2, 2, 1, 1000, 0.0, 0.0), (128, 128, 32, 8, 1, 4096, 0.0, 0.0),
+                                 (128, 128, 8, 2, 150, 336, 0.0, 0.0), (64, 64, 4, 2, 40, 96, 4.0, 0.0), (96, 96, 4, 4, 33, 80, 0.0, 5.0)], ids=str)   # (the last three: prefill batches)
 def test_flash_attn_ext(G, torch, cfg):
     """GGML_OP_FLASH_ATTN_EXT for an f16 KV cache against a float64 restatement of ggml-cpu/ops.cpp:6690-6905 (q rounded to f16 before
     the dot products; causal f16 mask with -inf; GQA; ALiBi slopes; logit soft-capping).  The reference's own harness checks the same op
@@ -203,4 +204,5 @@ def test_flash_attn_ext(G, torch, cfg):
         ref[0, :, h] = p @ v[0, hk].astype(np.float64)
     assert np.isfinite(y).all()
     err = np.abs(y - ref).max()
-    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (cfg, err)
+    # (prefill batches round the probabilities to f16 for the matrix cores: 2^-11 relative on each of them)
+    assert err <= (2e-5 if N < 16 or softcap else 4e-4) * max(1.0, np.abs(ref).max()), (cfg, err)

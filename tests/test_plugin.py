@@ -171,7 +171,7 @@ def test_fused_nodes_bit_identical_to_separate_nodes(n_tokens):
 
 @pytest.mark.gpu
 @needs_plugin
-@pytest.mark.parametrize("n_tokens", [1, 3])
+@pytest.mark.parametrize("n_tokens", [1, 3, 32])
 def test_decode_layer_with_flash_attention(n_tokens):
     """The same decoder layer built the way llama.cpp builds it with -fa 1 (one GGML_OP_FLASH_ATTN_EXT node on the f16 cache, V not
     transposed, f16 mask, window padded to 256): resident (no node refused) and equal to the CPU backend over a 12-step decode loop."""
