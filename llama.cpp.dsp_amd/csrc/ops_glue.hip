@@ -493,10 +493,12 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (mmf_f4) { 0.f, 0.f, 0.f, 0.f };
-    for (int64_t k0 = 0; k0 < K; k0 += MMF_K) {
+    // the operands of step k0 + 64 are loaded while the matrix cores work on step k0
+    uint4 a0, a1; float4 f0, f1, f2, f3;
+    auto fetch = [&](int64_t k0) {
         const int64_t ks = k0 + 16 * seg;
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-        float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0, f3 = f0;
+        a0 = make_uint4(0, 0, 0, 0); a1 = a0;
+        f0 = make_float4(0.f, 0.f, 0.f, 0.f); f1 = f0; f2 = f0; f3 = f0;
         if (ks < K) {                                                         // K is a multiple of 16 (checked by the launcher)
             if constexpr (!AT) { a0 = *(const uint4 *) (ap + 2 * ks); a1 = *(const uint4 *) (ap + 2 * ks + 16); }
             const float4 * bq = (const float4 *) (bp + 4 * ks);
@@ -508,6 +510,9 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const
                 a0 = *(const uint4 *) vp; a1 = *(const uint4 *) (vp + 16);
             }
         }
+    };
+    fetch(0);
+    for (int64_t k0 = 0; k0 < K; k0 += MMF_K) {
         __syncthreads();                                                      // the previous step's fragments have been read
         if constexpr (AT) {
             const uint32_t wv[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
@@ -523,6 +528,7 @@ __global__ void __launch_bounds__(256) k_mul_mat_f16_mfma(const TensorD a, const
         const mmf_h8 h1 = { (_Float16) f2.x, (_Float16) f2.y, (_Float16) f2.z, (_Float16) f2.w, (_Float16) f3.x, (_Float16) f3.y, (_Float16) f3.z, (_Float16) f3.w };
         *(mmf_h8 *) (Bs + row * MMF_LDS_ROW + 32 * seg) = h0; *(mmf_h8 *) (Bs + row * MMF_LDS_ROW + 32 * seg + 16) = h1;
         __syncthreads();
+        if (k0 + MMF_K < K) fetch(k0 + MMF_K);
 #pragma unroll
         for (int kk = 0; kk < MMF_K / 32; ++kk) {
             const int koff = 2 * (32 * kk + 8 * (lane >> 4));
