@@ -3,13 +3,14 @@
 
 One "step" = one generated token = one pass over every quantized matmul weight the token touches
 (32 x {attn_q, attn_k, attn_v, attn_output, ffn_gate, ffn_up, ffn_down} + output: 225 matrices, 4.616 GB,
-BASELINE.md section 3), N=1 activation column, in 4 dependent steps per layer (q/k/v fused, attn_output, gate/up
-fused, ffn_down) + 1.  Default (--launch plan): the whole token is ONE persistent cooperative launch
-(mi355q_plan_*: grid barriers between the dependent steps, weights prefetched across them); --launch graph:
-one launch per step (129), captured in a hipGraph.  Inputs (weights and activations) are resident in HBM before the
-timed region.  Non-matmul graph ops (norm, rope, attention, softmax...) are NOT part of this path and are not
-executed (they are the "next" rows): every step after the first is ordered behind the previous
-one exactly as the real graph orders them, but reads a pre-filled activation buffer.
+BASELINE.md section 3), N=1 activation column.  Default (--launch plan): the WHOLE decode step of the llama graph
+(src/llama-model.cpp llm_build_llama) is ONE persistent launch (mi355q_plan_*): per layer rms_norm*w -> q|k|v, rope +
+KV-cache store + causal attention over the f16 cache, attn_output, residual + rms_norm*w -> gate|up, SiLU*up -> down,
+then the output norm and the output matrix -- every value handed from stage to stage on the device, the token's position,
+window length, cache slots and mask uploaded per token as llama.cpp uploads its graph inputs, and a stream synchronize per
+token as llama-bench does (llama_decode + llama_synchronize).  The context grows from empty as in tg128.
+--launch graph: the quantized matmuls alone, one launch per step (129), captured in a hipGraph (round 1's path, no glue).
+Weights, KV cache and the token embedding input are resident in HBM before the timed region.
 
   python bench.py [--gpus N --steps K --warmup W]         (N>1: launched by torch.distributed.run)
 
@@ -109,6 +110,8 @@ class Stage:
                 plan = [[n] for grp in plan for n in grp]
             for grp in plan:
                 ws = [device_random_weight(torch, g, ss[n], device) for n in grp]
+                for w, n in zip(ws, grp):
+                    w.name = ss[n].name
                 nbytes = sum(ss[n].nbytes for n in grp)
                 if ws[0].n_expert > 1:
                     sp = ss[grp[0]]
@@ -123,9 +126,78 @@ class Stage:
                     self.groups.append((ws, x_for(ws[0].K), ys, nbytes, None))
                 self.bytes += nbytes
 
-    def make_plan(self):
-        """The same steps as ONE persistent launch; every step after the first waits (grid barrier) for the previous one."""
-        return self.g.Plan([(ws, x, ys, i > 0) for i, (ws, x, ys, _, _) in enumerate(self.groups)])
+    def make_decode_plan(self, cfg, x_in, n_ctx, last_rank):
+        """The llama decode step of this rank's layers as ONE persistent launch (see the module docstring).  x_in: the layer input
+        ([1, n_embd] f32: the token embedding, or the boundary activation received from the previous rank)."""
+        torch, g = self.torch, self.g
+        dev = x_in.device
+        E, F, nh, nkv, hd = cfg["n_embd"], cfg["n_ff"], cfg["n_head"], cfg["n_head_kv"], cfg["head_dim"]
+        kvd = nkv * hd
+        f32 = lambda n: torch.zeros((1, n), dtype=torch.float32, device=dev)
+        q, k, v, att, o, gate, up, d, hcur, ffn_inp = f32(E), f32(kvd), f32(kvd), f32(E), f32(E), f32(F), f32(F), f32(E), f32(E), f32(E)
+        by = {}
+        for ws, _, _, _, _ in self.groups:
+            for w in ws:
+                by[w.name] = w
+        layers = sorted({int(n.split(".")[1]) for n in by if n.startswith("blk.")})
+        L = len(layers)
+        # per-token parameters: ONE device block  [pos i32, n_kv i32 | k_dst, v_dst (L x 2 pointers) | mask f32 [n_ctx]]
+        off_dst, off_mask = 16, 16 + 16 * max(L, 1)
+        self.par_dev = torch.zeros(off_mask + 4 * n_ctx, dtype=torch.uint8, device=dev)
+        self.par_host = torch.zeros(off_mask + 4 * n_ctx, dtype=torch.uint8).pin_memory()
+        pos_d = self.par_dev[0:4].view(torch.int32); nkv_d = self.par_dev[4:8].view(torch.int32)
+        dst_d = self.par_dev[off_dst:off_mask].view(torch.int64).view(max(L, 1), 2)
+        mask_d = self.par_dev[off_mask:].view(torch.float32)
+        self.kc = [torch.zeros((n_ctx, kvd), dtype=torch.float16, device=dev) for _ in layers]
+        self.vc = [torch.zeros((kvd, n_ctx), dtype=torch.float16, device=dev) for _ in layers]          # transposed V cache (the non-flash graph)
+        self.norm_w = [(1.0 + 0.1 * torch.randn(E, device=dev)).float() for _ in range(2 * L + 1)]
+        self.n_ctx, self.kvd = n_ctx, kvd
+        import numpy as np
+        self._par = self.par_host.numpy()
+        self._kbase = np.array([t.data_ptr() for t in self.kc], np.int64); self._vbase = np.array([t.data_ptr() for t in self.vc], np.int64)
+        self._views = (off_dst, off_mask, L)
+        st = []
+        x0, x1 = x_in, None
+        for li, il in enumerate(layers):
+            W = lambda n: by[f"blk.{il}.{n}"]
+            last = li == L - 1
+            st.append(dict(ws=[W("attn_q"), W("attn_k"), W("attn_v")], ys=[q, k, v], x=x0, x1=x1, x_kind=g.X_NORM, norm_w=self.norm_w[2 * li], eps=1e-5,
+                           sum_out=hcur if x1 is not None else None, no_plain=True))
+            h_res = hcur if x1 is not None else x0
+            st.append(dict(attn=dict(q=q, k=k, v=v, pos=pos_d, n_kv_dev=nkv_d, rope=dict(n_dims=hd, mode=0, n_ctx_orig=8192, freq_base=500000.0),
+                                     k_cache=self.kc[li], v_cache=self.vc[li], k_nb_pos=kvd * 2, k_nb_head=hd * 2, v_nb_pos=2, v_nb_dim=n_ctx * 2,
+                                     v_nb_head=hd * n_ctx * 2, k_dst=dst_d[li, 0:1], v_dst=dst_d[li, 1:2], v_dst_nb=n_ctx * 2, mask=mask_d,
+                                     n_head=nh, n_head_kv=nkv, head_dim=hd, n_kv=n_ctx, scale=1.0 / hd ** 0.5, out=att), no_plain=True))
+            st.append(dict(ws=[W("attn_output")], ys=[o], x=att, no_plain=True))
+            st.append(dict(ws=[W("ffn_gate"), W("ffn_up")], ys=[gate, up], x=h_res, x1=o, x_kind=g.X_NORM, norm_w=self.norm_w[2 * li + 1], eps=1e-5,
+                           sum_out=ffn_inp, no_plain=not (last and not last_rank)))
+            st.append(dict(ws=[W("ffn_down")], ys=[d], x=gate, x1=up, x_kind=g.X_UNARY_MUL, unary=g.UNARY_SILU, no_plain=not (last and not last_rank)))
+            x0, x1 = ffn_inp, d
+        self.logits = None
+        if "output" in by:
+            self.logits = torch.zeros((1, by["output"].M), dtype=torch.float32, device=dev)
+            st.append(dict(ws=[by["output"]], ys=[self.logits], x=x0, x1=x1, x_kind=g.X_NORM, norm_w=self.norm_w[2 * L], eps=1e-5))
+        self.boundary = (ffn_inp, d) if L else None
+        self._keep = (q, k, v, att, o, gate, up, d, hcur, ffn_inp, x_in)
+        self.kv_bytes_per_pos = 2 * kvd * 2 * L
+        return g.Plan(st)
+
+    def set_token(self, pos):
+        """Upload the token's graph inputs (position, window length padded to 32 as llama_kv_cache_unified does, this token's cache slots,
+        the causal mask row) with ONE host-to-device copy."""
+        import numpy as np
+        off_dst, off_mask, L = self._views
+        n_kv = min(self.n_ctx, (pos + 1 + 31) // 32 * 32)
+        p = self._par
+        p[0:8].view(np.int32)[:] = (pos, n_kv)
+        dst = p[off_dst:off_mask].view(np.int64).reshape(max(L, 1), 2)
+        if L:
+            dst[:, 0] = self._kbase + pos * self.kvd * 2
+            dst[:, 1] = self._vbase + pos * 2
+        m = p[off_mask:].view(np.float32)
+        m[:] = -np.inf; m[:pos + 1] = 0.0
+        self.par_dev.copy_(self.par_host, non_blocking=True)
+        return n_kv
 
     def run_group(self, grp):
         g = self.g
@@ -140,6 +212,15 @@ class Stage:
     def run(self):
         for grp in self.groups:
             self.run_group(grp)
+
+
+def kernel_source_sha16():
+    """Hash of the sources of the dominant kernel (ties a committed PMC traffic figure to the code it was measured on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("plan.hip", "gemv_stream.cuh", "act_quant.cuh", "mi355q_common.h"):
+        h.update((ROOT / "llama.cpp.dsp_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
 
 
 def measured_hbm_read_GBps(torch, device):
@@ -160,7 +241,43 @@ def measured_hbm_read_GBps(torch, device):
         e0.record(); L.mi355q_tool_stream_read(buf.data_ptr(), nbytes, sink.data_ptr(), st); e1.record()
         torch.cuda.synchronize()
         best = max(best, nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del buf, sink
+    import _ctypes
+    h = L._handle
+    del L
+    _ctypes.dlclose(h)                                           # (unregisters its code object now, not from an exit handler)
     return round(best, 1)
+
+
+def verify_token0(torch, g, stage, plan, cfg, x_in):
+    """Before timing: the first token (empty context: attention returns the f16-rounded v of its kv head) through the plan must equal the same
+    chain issued node by node with the library's per-op entry points (mi355q_op_add_rms_norm_mul, mi355q_mul_mat, mi355q_op_unary_mul)."""
+    by = {w.name: w for grp in stage.groups for w in grp[0]}
+    layers = sorted({int(n.split(".")[1]) for n in by if n.startswith("blk.")})
+    nh, nkv, hd = cfg["n_head"], cfg["n_head_kv"], cfg["head_dim"]
+    stage.set_token(0)
+    plan.run(); torch.cuda.synchronize()
+    if plan.status() != 0:
+        raise RuntimeError("decode plan aborted (a poll timed out)")
+    h, dn = x_in, None
+    for li, il in enumerate(layers):
+        W = lambda n: by[f"blk.{il}.{n}"]
+        if dn is None:
+            x = g.op_add_rms_norm_mul(h, 1e-5, weight=stage.norm_w[2 * li])
+        else:
+            x, h = g.op_add_rms_norm_mul(h, 1e-5, b=dn, weight=stage.norm_w[2 * li], want_sum=True)
+        v = g.mul_mat(W("attn_v"), x)
+        att = v.view(nkv, 1, hd).half().float().expand(nkv, nh // nkv, hd).reshape(1, nh * hd).contiguous()
+        o = g.mul_mat(W("attn_output"), att)
+        x, ffn_inp = g.op_add_rms_norm_mul(h, 1e-5, b=o, weight=stage.norm_w[2 * li + 1], want_sum=True)
+        dn = g.mul_mat(W("ffn_down"), g.op_unary_mul(g.UNARY_SILU, g.mul_mat(W("ffn_gate"), x), g.mul_mat(W("ffn_up"), x)))
+        h = ffn_inp
+    x = g.op_add_rms_norm_mul(h, 1e-5, b=dn, weight=stage.norm_w[2 * len(layers)])
+    ref = g.mul_mat(by["output"], x)
+    torch.cuda.synchronize()
+    err = float((stage.logits - ref).abs().max() / ref.abs().max())
+    if not (err <= 1e-4):        # (equal up to the f64 summation order inside the norms and, across 32 layers, what that flips downstream)
+        raise RuntimeError(f"decode plan logits differ from the node-by-node path: {err:.3e}")
 
 
 def cpu_baseline(specs, seconds):
@@ -229,32 +346,34 @@ def main():
         if stage.has_moe and launch == "plan":
             launch = "graph"                                    # the decode plan covers MUL_MAT chains; MUL_MAT_ID runs per launch
         graph = plan = None
-        stage.run(); torch.cuda.synchronize()                  # warm every kernel / attribute (and the reference outputs for the plan check)
+        stage.run(); torch.cuda.synchronize()                  # warm every kernel / attribute
+        n_ctx = max(32, (max(a.steps, a.warmup) + 31) // 32 * 32)
         if launch == "graph":
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 stage.run()
         elif launch == "plan":
-            want = [[y.clone() for y in ys] for _, _, ys, _, _ in stage.groups]
-            plan = stage.make_plan()
-            for _, _, ys, _, _ in stage.groups:
-                for y in ys:
-                    y.zero_()
-            plan.run(); torch.cuda.synchronize()
-            if plan.status() != 0:
-                raise RuntimeError("decode plan aborted (grid barrier timeout)")
-            for (_, _, ys, _, _), ws_ in zip(stage.groups, want):  # the persistent launch computes exactly what the per-matmul launches do
-                for y, w_ in zip(ys, ws_):
-                    if not torch.equal(y.view(torch.int32), w_.view(torch.int32)):
-                        raise RuntimeError("decode plan output differs from the per-matmul launches")
-            del want
-        run_token = plan.run if plan is not None else (graph.replay if graph is not None else stage.run)
+            if rank == 0:
+                act.copy_(torch.randn_like(act))                # the token embedding (GET_ROWS of token_embd runs on the CPU in llama.cpp)
+            plan = stage.make_decode_plan(cfg, act, n_ctx, rank == world - 1)
+            if world == 1:
+                verify_token0(torch, g, stage, plan, cfg, act)
+        act_out = torch.zeros_like(act)
+        tok = [0]
         def token():
             if world > 1 and rank > 0:
-                dist.recv(act, src=rank - 1)                    # boundary activation from the previous stage
-            run_token()
-            if world > 1 and rank < world - 1:
-                dist.send(act, dst=rank + 1)
+                dist.recv(act, src=rank - 1)                    # boundary activation from the previous stage: the first norm of this rank reads it
+            if plan is not None:
+                stage.set_token(tok[0] % n_ctx); tok[0] += 1
+                plan.run()
+                if world > 1 and rank < world - 1:
+                    torch.add(stage.boundary[0], stage.boundary[1], out=act_out)       # the layer output h = ffn_inp + ffn_down
+                    dist.send(act_out, dst=rank + 1)
+                torch.cuda.current_stream().synchronize()       # llama-bench: llama_decode + llama_synchronize per generated token
+            else:
+                (graph.replay if graph is not None else stage.run)()
+                if world > 1 and rank < world - 1:
+                    dist.send(act, dst=rank + 1)
 
     def sync():
         if not a.dry_run:
@@ -267,6 +386,8 @@ def main():
     for _ in range(a.warmup):
         token()
     sync()
+    if not a.dry_run:
+        tok[0] = 0                                              # tg: the timed tokens start from an empty context
     t0 = time.perf_counter()
     for _ in range(a.steps):
         token()
@@ -278,16 +399,17 @@ def main():
         dt = float(tmax.item())
 
     out = {
-        "metric": "llama-bench tg128 tok/s (quantized-matmul hot path), " + {"llama3-8b": "Llama-3-8B", "llama3-70b": "Llama-3-70B", "mixtral-8x7b": "Mixtral-8x7B"}[a.model] + " " + a.ftype,
+        "metric": "llama-bench tg128 tok/s (decode step at the C-ABI of the quantized-matmul hot path), " + {"llama3-8b": "Llama-3-8B", "llama3-70b": "Llama-3-70B", "mixtral-8x7b": "Mixtral-8x7B"}[a.model] + " " + a.ftype,
         "value": round(a.steps / dt, 2), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int8",
         "data": "synthetic (random packed blocks with finite scales, gaussian activations)",
         "config": {"workload": f"{a.model} {a.ftype} tg (N=1): all {len(specs)} quantized mul_mat{'/mul_mat_id' if stage is not None and stage.has_moe else ''} weights per token, "
                                f"{total_bytes / 1e9:.3f} GB/token; {'fused q|k|v and gate|up steps, ' if not a.no_fuse else ''}"
-                               + {"plan": "one persistent cooperative launch per token (grid barrier between dependent steps)",
-                                  "graph": "one launch per step, hipGraph replay", "eager": "one launch per step, eager"}[launch if not a.dry_run else "eager"]
-                               + "; non-matmul graph ops not executed",
+                               + {"plan": "the whole llama decode step (norms, rope, KV store, attention over the growing f16 cache, SiLU, residuals, output matrix) as one persistent launch per token, "
+                                          "stage-to-stage hand-off by tagged granules, graph inputs uploaded and the stream synchronized per token as llama-bench does",
+                                  "graph": "one launch per matmul step, hipGraph replay; non-matmul graph ops not executed",
+                                  "eager": "one launch per matmul step, eager; non-matmul graph ops not executed"}[launch if not a.dry_run else "eager"],
                    "bytes_per_token": total_bytes,
                    "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs (RCCL send/recv of the boundary activation)"},
     }
@@ -318,31 +440,36 @@ def main():
             with torch.cuda.graph(cg):
                 run_class()
             secs = timed(cg.replay, 20)
+            del cg
             nb = sum(t[3] for t in grp)
             per_kernel[f"k_gemv_fast<{tname}, K={kk}, N=1>"] = {"launches_per_token": len(grp), "bytes_per_token": nb, "avg_launch_us": round(1e6 * secs / len(grp), 2),
                                                                 "algorithmic_bytes_per_launch": nb // len(grp), "GBps": round(nb / secs / 1e9, 1)}
         if plan is not None:
-            # (b) the persistent launch IS the token: one kernel, algorithmic bytes = every weight byte of this rank's layers
+            # (b) the persistent launch IS the token: one kernel; algorithmic bytes = every weight byte of this rank's layers + the K / V
+            # cache window the token attends to (here the longest one of the run)
+            n_kv_t = stage.set_token(n_ctx - 1)
             secs = timed(plan.run, 20)
             if plan.status() != 0:
-                raise RuntimeError("decode plan aborted (grid barrier timeout)")
-            dom_name = "k_plan (persistent decode plan, %d steps)" % plan.launch_stages
-            dom = {"launches_per_token": 1, "bytes_per_token": stage.bytes, "avg_launch_us": round(1e6 * secs, 2),
-                   "algorithmic_bytes_per_launch": stage.bytes, "GBps": round(stage.bytes / secs / 1e9, 1)}
+                raise RuntimeError("decode plan aborted (a poll timed out)")
+            alg = stage.bytes + stage.kv_bytes_per_pos * n_kv_t
+            dom_name = "k_plan (persistent decode plan, %d stages)" % plan.launch_stages
+            dom = {"launches_per_token": 1, "bytes_per_token": alg, "avg_launch_us": round(1e6 * secs, 2), "n_kv": n_kv_t,
+                   "algorithmic_bytes_per_launch": alg, "GBps": round(alg / secs / 1e9, 1)}
             all_kernels = {dom_name: dom, "per_matmul_launch_path_for_comparison": per_kernel}
         else:
             dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["bytes_per_token"])
             all_kernels = per_kernel
         achieved = dom["GBps"]
-        # HBM bytes per launch from the PMC pass of this same command (rocprofv3 cannot run inside the timed process; the
-        # committed summary of the separate --pmc FETCH_SIZE pass is quoted, with its source, when it covers this kernel)
+        # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE pass of this same command (a profiler cannot run inside
+        # the timed process).  The committed summary is quoted ONLY while it was taken from the kernel sources as they are now (their
+        # hash is stored with it); otherwise null -- never a stale number.
         traffic, traffic_src = None, None
-        if plan is not None and a.ftype == "Q4_K_M" and world == 1:
+        if plan is not None and a.ftype == "Q4_K_M" and a.model == "llama3-8b" and world == 1:
             for tf in sorted((ROOT / "profiles").glob("round*_traffic.json"), reverse=True):
                 try:
                     tj = json.loads(tf.read_text())
                     vals = [v for k, v in tj.get("kernels", {}).items() if k.startswith("k_plan")]
-                    if vals:
+                    if vals and tj.get("kernel_source_sha16") == kernel_source_sha16():
                         traffic, traffic_src = int(vals[0]), f"{tj.get('source')}: {tj.get('method')}"
                         break
                 except Exception:
@@ -394,11 +521,23 @@ def main():
             except Exception as e:                              # the baseline is a report, never a reason to fail the bench
                 out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out))
-    if not a.dry_run and plan is not None:
-        plan.close()                                            # before interpreter teardown (the HIP runtime unloads first under profilers)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not a.dry_run:
+        # Explicit, ordered teardown (nothing that owns HIP resources is left to interpreter exit / library finalizers): launch graphs and
+        # events first, then the plan, the weights, the cached workspaces; synchronize; unload the HIP library while the runtime is alive.
+        import gc
+        if plan is not None:
+            plan.close()
+        graph = plan = run_token = token = None
+        stage.groups.clear(); stage = None
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        g.shutdown()
+        if os.environ.get("MI355Q_LOG_MAPS"):                   # attribution of exit-time frames (diagnostic)
+            Path(os.environ["MI355Q_LOG_MAPS"]).write_text(Path("/proc/self/maps").read_text())
 
 
 if __name__ == "__main__":

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_API_VERSION 1
+#define MI355Q_API_VERSION 2
 
 /* error codes */
 #define MI355Q_OK                0
@@ -110,6 +110,17 @@ int mi355q_memset(void *dev_ptr, int value, size_t bytes, void *stream);
 int mi355q_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);   /* stream NULL: synchronous */
 int mi355q_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int mi355q_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+/* pinned (page-locked) host memory: staging for asynchronous set/get_tensor, ggml's host buffer type (ggml-backend-impl.h:137-185 get_host_buffer_type) */
+int mi355q_host_malloc(void **host_ptr, size_t bytes);
+int mi355q_host_free(void *host_ptr);
+/* copy between two devices of this process (hipMemcpyPeerAsync: xGMI where the devices are linked), ordered on `stream` of the CURRENT device */
+int mi355q_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, void *stream);
+/* events (ggml_backend_event_*: ggml-backend-impl.h:87-124 event_record / event_wait, :137-185 event_new / event_free / event_synchronize) */
+int mi355q_event_create(void **event);
+int mi355q_event_destroy(void *event);
+int mi355q_event_record(void *event, void *stream);
+int mi355q_event_wait(void *stream, void *event);           /* makes `stream` (of any device) wait for the event */
+int mi355q_event_synchronize(void *event);
 int mi355q_stream_create(void **stream);
 int mi355q_stream_destroy(void *stream);
 int mi355q_stream_synchronize(void *stream);
@@ -175,29 +186,88 @@ int    mi355q_mul_mat_id(int type, const void *w, int64_t w_stride_bytes, int64_
                          float *y, int64_t m, int64_t k, int64_t n_used, int64_t n_tok,
                          void *workspace, size_t workspace_bytes, int flags, void *stream);
 
-/* ---- decode plan: a chain of N=1 MUL_MATs as ONE persistent launch --------------------------------------
+/* ---- decode plan: the token's dependent chain as ONE persistent launch ----------------------------------------------
  * Replaces the reference's per-node launches + CUDA-graph replay of the token-generation graph
- * (ggml-cuda.cu:2470-2781, evaluate_and_capture_cuda_graph / ggml_backend_cuda_graph_compute) for the
- * MUL_MAT nodes of a decode step.  A STAGE is 1..4 weight matrices (planar device rows, types may differ)
- * against one f32 activation vector x[k]; y_i[m_i] = W_i . x exactly as mi355q_mul_mat computes it
- * (bit-identical).  Stages run in order inside one cooperative launch; the weight stream continues across
- * stage boundaries.  MI355Q_STAGE_DEPENDS: x of this stage is written (directly, or by another agent on the
- * same device before it is read) from results of EARLIER stages of the same run -> a grid-wide barrier
- * orders it.  Without the flag x must be complete before the launch.
- * Only types with a planar layout at this k (mi355q_weights_are_planar) are accepted.
- * run(): asynchronous on `stream`.  status(): synchronizes; 1 = a barrier timed out (plan unusable). */
-#define MI355Q_STAGE_DEPENDS 0x1
+ * (ggml-cuda.cu:2470-2781, evaluate_and_capture_cuda_graph / ggml_backend_cuda_graph_compute): the N = 1 nodes of a
+ * decode step -- the quantized MUL_MATs AND the glue between them -- run as an ordered list of STAGES inside one
+ * cooperative launch of one workgroup per CU.
+ *
+ * GEMV stage: 1..4 weight matrices (planar device rows, types may differ) against one activation vector x[k];
+ *   y_i[m_i] = W_i . x exactly as mi355q_mul_mat computes it (bit-identical for the same x).  x is formed in the
+ *   stage's prologue from f32 vectors of k elements (every workgroup does it for itself, into LDS):
+ *     MI355Q_X_PLAIN      x = x0
+ *     MI355Q_X_NORM       t = x0 (+ x1);  [sum_out = t;]  x = rms_norm(t, eps) (* norm_w)     ADD -> RMS_NORM -> MUL of build_norm
+ *     MI355Q_X_UNARY_MUL  x = unary(x0) * x1      (x_unary: MI355Q_UNARY_SILU / _RELU / _SIGMOID)   build_ffn LLM_FFN_SILU + LLM_FFN_PAR
+ *   with the f32 operations of the CPU ops (same expressions as mi355q_op_add_rms_norm_mul / mi355q_op_unary_mul).
+ * ATTN stage: rope of q and k, the K / V cache stores of this token and causal attention of ONE token over an f16 KV cache
+ *   (ROPE, CPY, MUL_MAT(k,q), SOFT_MAX, MUL_MAT(v,kq) / FLASH_ATTN_EXT of build_attn_mha, src/llama-graph.cpp:1140-1260): see mi355q_attn.
+ *
+ * Dependencies are DATA-DRIVEN: an operand (x0, x1, q, k, v) whose address range lies inside an output (mats[i].y, sum_out,
+ * attn.out) of an EARLIER stage of the plan is a value produced during the run: the producers publish every element as an
+ * 8-byte {value, tag} granule in a plan-private buffer and the consumers poll the granules they need -- there is no grid-wide
+ * barrier and no flag.  Any other operand must be complete before the launch.  Weights stream across stage boundaries.
+ * Plain f32 copies of the outputs are stored at mats[i].y / sum_out / attn.out unless MI355Q_STAGE_NO_PLAIN is set (set it for
+ * intermediates nobody outside the plan reads: a caller whose allocator reuses their memory must).
+ * Only weight types with a planar layout at this k (mi355q_weights_are_planar) are accepted.
+ * run(): asynchronous on `stream`.  status(): synchronizes; 1 = a poll timed out (plan unusable).                         */
+#define MI355Q_STAGE_DEPENDS  0x1    /* (API version 1; accepted and ignored: dependencies follow from the operand addresses) */
+#define MI355Q_STAGE_NO_PLAIN 0x2    /* do not store plain f32 copies of this stage's outputs                               */
+#define MI355Q_STAGE_GEMV 0
+#define MI355Q_STAGE_ATTN 1
+#define MI355Q_X_PLAIN     0
+#define MI355Q_X_NORM      1
+#define MI355Q_X_UNARY_MUL 2
+typedef struct mi355q_rope_params {      /* the op_params of GGML_OP_ROPE (ggml.c ggml_rope_impl) */
+    int   n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} mi355q_rope_params;
+/* One token's attention.  q [n_head*head_dim], k, v [n_head_kv*head_dim]: f32 outputs of earlier stages (or complete before the launch).
+ * Cache element (position j, dim d, kv head g) is an f16 at  k_cache + j*k_nb_pos + g*k_nb_head + 2*d   and
+ * v_cache + j*v_nb_pos + d*v_nb_dim + g*v_nb_head  (v_nb_dim == 2: rows per position, the -fa layout; v_nb_pos == 2: the transposed
+ * V cache of the non-flash graph).  This token's roped K row (f16, n_head_kv*head_dim contiguous) is stored at *k_dst and element
+ * e of its V row at *v_dst + e*v_dst_nb; k_dst / v_dst are DEVICE slots holding the destination pointers, so that the caller moves the
+ * store position every token without rebuilding the plan (cf. mi355q_op_cpy_indirect); the token attends to positions [0, n_kv) with
+ * the additive mask row `mask` (f32 or f16, n_kv entries, may be NULL = no masking), as soft_max_ext(kq*scale + mask) does; the row
+ * being stored is read from the registers, not from the cache.  out [n_head*head_dim] f32.  rope.mode 0 (normal) or 2 (neox).           */
+typedef struct mi355q_attn {
+    const float   *q, *k, *v;
+    const int32_t *pos;              /* device: the token's position (rope angle)                */
+    mi355q_rope_params rope;
+    const float   *freq_factors;     /* optional rope frequency factors [n_dims/2]               */
+    const void    *k_cache, *v_cache;
+    int64_t        k_nb_pos, k_nb_head, v_nb_pos, v_nb_dim, v_nb_head;
+    void * const  *k_dst, * const *v_dst;
+    int64_t        v_dst_nb;
+    const void    *mask;
+    int            mask_f16;
+    int            n_head, n_head_kv, head_dim, n_kv;
+    float          scale;
+    float         *out;
+    const int32_t *n_kv_dev;         /* optional, device: the window length of THIS run (<= n_kv, which then is the maximum the plan is sized for) */
+} mi355q_attn;
 typedef struct mi355q_stage {
-    mi355q_mat   mats[4];    /* y_stride is unused (one activation row) */
+    mi355q_mat   mats[4];    /* GEMV: y_stride is unused (one activation row) */
     int          n_mats;
     int          flags;
-    const float *x;          /* device, k floats */
+    const float *x;          /* GEMV: x0, device, k floats */
     int64_t      k;
+    /* --- API version 2 --- */
+    int          kind;       /* MI355Q_STAGE_GEMV (0) / MI355Q_STAGE_ATTN */
+    int          x_kind;     /* MI355Q_X_* */
+    int          x_unary;
+    float        eps;
+    const float *x1;         /* second operand (X_NORM: optional addend; X_UNARY_MUL: the multiplier) */
+    const float *norm_w;     /* X_NORM: optional weight vector [k] (complete before the launch)        */
+    float       *sum_out;    /* X_NORM with x1: where t = x0 + x1 is stored (the next residual's operand), optional */
+    const mi355q_attn *attn; /* MI355Q_STAGE_ATTN */
 } mi355q_stage;
 typedef struct mi355q_plan mi355q_plan;
 int     mi355q_plan_create(mi355q_plan **out, const mi355q_stage *stages, int n_stages, int flags);
 int     mi355q_plan_run(mi355q_plan *plan, void *stream);
 int     mi355q_plan_status(mi355q_plan *plan);
+/* asynchronous form: enqueues a 4-byte device-to-host copy of the plan's abort word into *host_flag (pinned memory recommended) on `stream`;
+ * after the stream has been synchronized, *host_flag != 0 means a poll of an earlier run timed out.                                       */
+int     mi355q_plan_status_async(mi355q_plan *plan, unsigned *host_flag, void *stream);
 int64_t mi355q_plan_weight_bytes(const mi355q_plan *plan);
 int     mi355q_plan_launch_stages(const mi355q_plan *plan);
 int     mi355q_plan_destroy(mi355q_plan *plan);
@@ -256,10 +326,6 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor *q, const mi355q_tensor *k, con
                              void *workspace, size_t workspace_bytes, void *stream);
 int mi355q_op_cpy(const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
 int mi355q_op_soft_max(const mi355q_tensor *a, const mi355q_tensor *mask, const mi355q_tensor *dst, float scale, float max_bias, void *stream);
-typedef struct mi355q_rope_params {      /* the op_params of GGML_OP_ROPE (ggml.c ggml_rope_impl) */
-    int   n_dims, mode, n_ctx_orig;
-    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
-} mi355q_rope_params;
 int mi355q_op_rope(const mi355q_tensor *a, const int32_t *pos, const float *freq_factors, const mi355q_tensor *dst,
                    const mi355q_rope_params *p, void *stream);
 int mi355q_op_mul_mat_f(const mi355q_tensor *a, const mi355q_tensor *b, const mi355q_tensor *dst, void *stream);

@@ -23,6 +23,7 @@
 
 #include "mi355q.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -39,6 +40,12 @@
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ contexts
+struct mi355_plan_entry {               // a decode plan cached per graph key (decode-plan.inc)
+    uint64_t key = 0;
+    mi355q_plan * plan = nullptr;
+    std::vector<int> pre, post;         // node indices issued eagerly before / after the launch
+    int n_stages = 0;
+};
 struct mi355_device_ctx {
     int         index;
     std::string name;          // "MI355_0"
@@ -65,10 +72,17 @@ struct mi355_backend_ctx {
     int         key_changes = 0;        // consecutive key changes: after a few the cache is given up for this backend
     bool        graphs_disabled = false;
     void **     dest_table = nullptr;   // device array: destination base pointers of the CPY nodes (updated every compute)
+    bool        dest_valid = false;     // the table holds THIS call's pointers (set by graph_compute after the upload, cleared on return)
     std::vector<void *> dest_host;
     bool        capturing = false;
     long        n_eager = 0, n_captured = 0, n_replayed = 0;   // graph_compute calls by how they ran (MI355_GRAPH_STATS=1 prints them)
     long        n_fused_norm = 0, n_fused_mats = 0, n_fused_act = 0, n_elided_cont = 0, n_fused_add = 0;   // launches saved by the fusions of mi355_issue_nodes
+    // decode plans (decode-plan.inc): the N = 1 graph as one persistent launch, cached per graph key
+    std::vector<struct mi355_plan_entry *> plans;
+    uint64_t    plan_declined_key = 0;
+    unsigned *  plan_abort = nullptr;   // pinned host word: != 0 once a plan's poll timed out
+    bool        plans_disabled = false;
+    long        n_planned = 0, n_plans_built = 0;
 };
 constexpr int MI355_MAX_CPY_DESTS = 4096;
 
@@ -216,6 +230,9 @@ static void * mi355_workspace(mi355_backend_ctx * ctx, size_t bytes) {
     GGML_ASSERT(!ctx->capturing && "workspace must be sized before a launch graph is captured");
     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
     if (ctx->workspace) mi355q_free(ctx->workspace);
+    // a captured launch graph holds the old workspace pointer in its kernel arguments: it must not be replayed
+    if (ctx->graph) { mi355q_graph_destroy(ctx->graph); ctx->graph = nullptr; }
+    ctx->graph_key = 0; ctx->key_repeats = 0;
     const size_t want = bytes + (bytes >> 2) + (1u << 20);
     MQ_CHECK(mi355q_malloc(&ctx->workspace, want));
     ctx->workspace_size = want;
@@ -272,16 +289,24 @@ static void mi355_backend_free(ggml_backend_t backend) {
         fprintf(stderr, "MI355 fusions (launches saved while issuing nodes): %ld norm*weight, %ld joined matmuls, %ld act*mul, %ld elided CONT, %ld add+norm\n",
                 ctx->n_fused_norm, ctx->n_fused_mats, ctx->n_fused_act, ctx->n_elided_cont, ctx->n_fused_add);
     }
+    if (getenv("MI355_GRAPH_STATS")) fprintf(stderr, "MI355 decode plans: %ld graph_compute calls ran as one persistent launch, %ld plans built\n", ctx->n_planned, ctx->n_plans_built);
+    for (mi355_plan_entry * e : ctx->plans) { mi355q_plan_destroy(e->plan); delete e; }
+    if (ctx->plan_abort) mi355q_host_free(ctx->plan_abort);
     if (ctx->graph) mi355q_graph_destroy(ctx->graph);
     if (ctx->dest_table) mi355q_free(ctx->dest_table);
     delete ctx;
     delete backend;
 }
 
+static void mi355_check_plan_abort(mi355_backend_ctx * ctx) {
+    if (ctx->plan_abort && *ctx->plan_abort) GGML_ABORT("MI355: a decode plan timed out waiting for its producers (another persistent kernel holding CUs?); set MI355_NO_PLAN=1");
+}
+
 static void mi355_backend_synchronize(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+    mi355_check_plan_abort(ctx);
 }
 
 // ---- residency ops: thin wrappers over mi355q_op_* -- the tensor descriptor is ggml's ne[] / nb[] verbatim
@@ -468,9 +493,15 @@ static bool mi355_joinable_mat(const struct ggml_tensor * n) {
            mi355q_weights_are_planar((int) w->type, w->ne[0]) == 1;
 }
 
-static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_cgraph * cgraph) {
+static bool mi355_operand_ok(const struct ggml_tensor * t);
+#include "decode-plan.inc"
+
+// `only`: issue just these nodes (the prefix / suffix around a decode plan), one by one without fusions
+static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_cgraph * cgraph, const std::vector<int> * only = nullptr) {
     static const bool no_fusion = getenv("MI355_NO_FUSION") != nullptr;
-    const bool fuse = !no_fusion && cgraph->n_nodes >= 4;
+    const bool fuse = !no_fusion && cgraph->n_nodes >= 4 && !only;
+    std::vector<char> want;
+    if (only) { want.assign((size_t) cgraph->n_nodes, 0); for (int i : *only) want[(size_t) i] = 1; }
     mi355_fuser * fz = fuse ? new mi355_fuser(cgraph) : nullptr;
     struct fz_guard { mi355_fuser * p; ~fz_guard() { delete p; } } guard{ fz };
     int cpy_index = 0;
@@ -478,6 +509,7 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
         struct ggml_tensor * node = cgraph->nodes[i];
         if (ggml_is_empty(node)) continue;
         if (node->op == GGML_OP_CPY) ++cpy_index;                 // (CPY nodes are never fused: their table slot is their ordinal)
+        if (only && !want[(size_t) i]) continue;
         if (fz && fz->done[(size_t) i]) continue;
         switch (node->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
@@ -515,7 +547,9 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
             break;
         case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); break;
         case GGML_OP_CPY:
-            mi355_glue_op(ctx, node, ctx->dest_table && cpy_index - 1 < MI355_MAX_CPY_DESTS ? cpy_index - 1 : -1);
+            // the indirect form only when the table was uploaded by THIS graph_compute call (a stale table would send the K / V rows
+            // of this token to an earlier call's cache slots)
+            mi355_glue_op(ctx, node, ctx->dest_valid && cpy_index - 1 < MI355_MAX_CPY_DESTS ? cpy_index - 1 : -1);
             break;
         case GGML_OP_RMS_NORM: {
             const int j = fz ? fz->next_compute(i) : -1;          // RMS_NORM -> MUL by a [ne0] weight vector
@@ -523,7 +557,8 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
                 struct ggml_tensor * mul = cgraph->nodes[j];
                 const struct ggml_tensor * w = mul->src[0] == node ? mul->src[1] : (mul->src[1] == node ? mul->src[0] : nullptr);
                 if (w && w != node && w->type == GGML_TYPE_F32 && ggml_is_contiguous(w) && w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] &&
-                    ggml_are_same_shape(mul, node) && mul->nb[0] == 4 && node->src[0]->nb[0] == 4 && fz->ready_before(w, i)) {
+                    ggml_are_same_shape(mul, node) && mul->nb[0] == 4 && node->src[0]->nb[0] == 4 && fz->ready_before(w, i) &&
+                    (mul->data == node->src[0]->data || !mi355_overlap(node->src[0], mul)) && !mi355_overlap(w, mul)) {   // in place or disjoint: rows are written while others are read
                     float eps; memcpy(&eps, node->op_params, sizeof(float));
                     const mi355q_tensor a = mi355_td(node->src[0]), d = mi355_td(mul);
                     MQ_CHECK(mi355q_op_add_rms_norm_mul(&a, nullptr, nullptr, (const float *) w->data, &d, eps, ctx->stream));
@@ -606,15 +641,18 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
+    mi355_check_plan_abort(ctx);
     static const bool env_off = getenv("MI355_NO_GRAPHS") != nullptr;
+    static const bool env_no_plan = getenv("MI355_NO_PLAN") != nullptr;
     bool try_graphs = !env_off && !ctx->graphs_disabled && cgraph->n_nodes >= 8;
+    const bool try_plan = !env_no_plan && !ctx->plans_disabled && cgraph->n_nodes >= 8;
     // a prefill-sized MUL_MAT_ID groups its rows by expert on the host (a stream synchronize inside): such a graph cannot be captured
     for (int i = 0; try_graphs && i < cgraph->n_nodes; ++i)
         if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT_ID && cgraph->nodes[i]->src[2]->ne[0] * cgraph->nodes[i]->src[2]->ne[1] >= 17) try_graphs = false;
 
     // destination pointers of the CPY nodes of THIS call
     int n_cpy = 0;
-    if (try_graphs) {
+    if (try_graphs || try_plan) {
         ctx->dest_host.clear();
         for (int i = 0; i < cgraph->n_nodes; ++i) if (cgraph->nodes[i]->op == GGML_OP_CPY && !ggml_is_empty(cgraph->nodes[i])) ctx->dest_host.push_back(cgraph->nodes[i]->data);
         n_cpy = (int) ctx->dest_host.size();
@@ -624,10 +662,41 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
             MQ_CHECK(mi355q_memcpy_h2d(ctx->dest_table, ctx->dest_host.data(), sizeof(void *) * n_cpy, ctx->stream));
         }
     }
+    ctx->dest_valid = n_cpy > 0;
     enum ggml_status st = GGML_STATUS_SUCCESS;
     bool done = false;
-    if (try_graphs && n_cpy >= 0) {
-        const uint64_t key = mi355_graph_key(cgraph);
+    uint64_t key = 0;
+    if ((try_graphs || try_plan) && n_cpy >= 0) key = mi355_graph_key(cgraph);
+
+    // ---- the whole decode step as ONE persistent launch (decode-plan.inc), cached per graph key
+    if (try_plan && n_cpy >= 0) {
+        mi355_plan_entry * e = nullptr;
+        for (size_t i = 0; i < ctx->plans.size(); ++i) if (ctx->plans[i]->key == key) { e = ctx->plans[i]; if (i) std::swap(ctx->plans[i], ctx->plans[0]); break; }
+        if (!e && key != ctx->plan_declined_key) {
+            mi355_plan_entry * ne = new mi355_plan_entry();
+            if (mi355_plan_compile(ctx, cgraph, *ne)) {
+                ne->key = key;
+                if (ctx->plans.size() >= 4) {                      // evict the least recently used plan (its launches must have finished)
+                    MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+                    mi355q_plan_destroy(ctx->plans.back()->plan); delete ctx->plans.back(); ctx->plans.pop_back();
+                }
+                ctx->plans.insert(ctx->plans.begin(), ne);
+                e = ne; ++ctx->n_plans_built;
+            } else { delete ne; ctx->plan_declined_key = key; }
+        }
+        if (e) {
+            if (!ctx->plan_abort) { MQ_CHECK(mi355q_host_malloc((void **) &ctx->plan_abort, 64)); *ctx->plan_abort = 0; }
+            if (!e->pre.empty()) st = mi355_issue_nodes(ctx, cgraph, &e->pre);
+            if (st == GGML_STATUS_SUCCESS) {
+                MQ_CHECK(mi355q_plan_run(e->plan, ctx->stream));
+                MQ_CHECK(mi355q_plan_status_async(e->plan, ctx->plan_abort, ctx->stream));
+                if (!e->post.empty()) st = mi355_issue_nodes(ctx, cgraph, &e->post);
+            }
+            done = true; ++ctx->n_planned;
+        }
+    }
+
+    if (!done && try_graphs && n_cpy >= 0) {
         if (key == ctx->graph_key) { ++ctx->key_repeats; ctx->key_changes = 0; }
         else {
             if (ctx->graph) { mi355q_graph_destroy(ctx->graph); ctx->graph = nullptr; }
@@ -657,10 +726,10 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
         }
     }
     if (!done) { st = mi355_issue_nodes(ctx, cgraph); ++ctx->n_eager; }
-    if (st != GGML_STATUS_SUCCESS) return st;
-    // set_tensor/get_tensor of this backend are synchronous copies on the null stream: finish the work before returning
-    MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
-    return GGML_STATUS_SUCCESS;
+    ctx->dest_valid = false;
+    // The work is left running on the backend's stream: ggml_backend_graph_compute() synchronizes after this call and the asynchronous form's
+    // callers call ggml_backend_synchronize() before they touch results (ggml-backend.cpp ggml_backend_graph_compute / _async), as with ggml-cuda.
+    return st;
 }
 
 static const struct ggml_backend_i mi355_backend_iface = {

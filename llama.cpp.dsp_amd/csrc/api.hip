@@ -135,6 +135,18 @@ static int copy(void * dst, const void * src, size_t bytes, hipMemcpyKind kind, 
 int mi355q_memcpy_h2d(void * d, const void * s, size_t n, void * st) { return copy(d, s, n, hipMemcpyHostToDevice, st); }
 int mi355q_memcpy_d2h(void * d, const void * s, size_t n, void * st) { return copy(d, s, n, hipMemcpyDeviceToHost, st); }
 int mi355q_memcpy_d2d(void * d, const void * s, size_t n, void * st) { return copy(d, s, n, hipMemcpyDeviceToDevice, st); }
+int mi355q_host_malloc(void ** p, size_t bytes) { HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocDefault)); return MI355Q_OK; }
+int mi355q_host_free(void * p) { HIP_TRY(hipHostFree(p)); return MI355Q_OK; }
+int mi355q_memcpy_peer(void * dst, int dst_device, const void * src, int src_device, size_t bytes, void * stream) {
+    if (dst_device == src_device) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream)); }
+    else                          { HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t) stream)); }
+    return MI355Q_OK;
+}
+int mi355q_event_create(void ** e) { hipEvent_t h; HIP_TRY(hipEventCreateWithFlags(&h, hipEventDisableTiming)); *e = h; return MI355Q_OK; }
+int mi355q_event_destroy(void * e) { HIP_TRY(hipEventDestroy((hipEvent_t) e)); return MI355Q_OK; }
+int mi355q_event_record(void * e, void * s) { HIP_TRY(hipEventRecord((hipEvent_t) e, (hipStream_t) s)); return MI355Q_OK; }
+int mi355q_event_wait(void * s, void * e) { HIP_TRY(hipStreamWaitEvent((hipStream_t) s, (hipEvent_t) e, 0)); return MI355Q_OK; }
+int mi355q_event_synchronize(void * e) { HIP_TRY(hipEventSynchronize((hipEvent_t) e)); return MI355Q_OK; }
 int mi355q_stream_create(void ** s) { hipStream_t h; HIP_TRY(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = h; return MI355Q_OK; }
 int mi355q_stream_destroy(void * s) { HIP_TRY(hipStreamDestroy((hipStream_t) s)); return MI355Q_OK; }
 int mi355q_stream_synchronize(void * s) { HIP_TRY(hipStreamSynchronize((hipStream_t) s)); return MI355Q_OK; }

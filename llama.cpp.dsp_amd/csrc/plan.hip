@@ -1,31 +1,31 @@
-// plan.hip -- the token-generation chain as ONE persistent launch (MI355X-first replacement for the
-// reference's "one kernel per node + CUDA graph" decode loop, ggml-cuda.cu:2470-2781).
+// plan.hip -- a token-generation step as ONE persistent launch (MI355X-first replacement for the reference's "one kernel
+// per node + CUDA graph" decode loop, ggml-cuda.cu:2470-2781): the N = 1 quantized matmuls AND the glue between them.
 //
-// A PLAN is an ordered list of STAGES; a stage = up to 4 planar weight matrices of one type that share an
-// activation vector x (N = 1), e.g. wq|wk of a layer, or ffn_gate|ffn_up.  One cooperative launch of
-// #CU workgroups (16 waves each, one per CU) walks the whole list:
+// A PLAN is an ordered list of STAGES, walked by every workgroup of one launch of #CU workgroups x 16 waves (one per CU, all resident):
 //
-//   * the weight stream never stops at a matmul boundary.  Weights do not depend on activations, so
-//     a wave requests the first chunks of its rows of stage s+1 as soon as it has finished its rows of
-//     stage s -- BEFORE the grid barrier that orders the activations -- and they are in flight during
-//     the barrier and the activation quantization.  (A per-matmul launch pays kernel boundary +
-//     dispatch + ring prime + quantize prologue serially, ~5-8 us)
-//   * the dependency between stages (y of one feeds, through the graph's glue ops, x of the next) is a
-//     grid barrier in device memory: two-level arrive counters (no cache line is touched by more than
-//     ~32 workgroups: one counter hammered by 256 pollers costs 5-20 us per barrier on this chip), relaxed
-//     agent-scope atomics, polled by one wave.  Outputs are written with agent-scope (sc1, write-through)
-//     stores and acknowledged (vmcnt) before the arrival; activations are read with sc1 loads, so no cache
-//     invalidate / write-back fences (which would also drain the in-flight weight loads) are needed.
-//   * a stage that reuses the previous stage's x (Q4_K wq|wk followed by Q6_K wv of a Q4_K_M layer)
-//     needs neither barrier nor re-quantization: the LDS image stays.
-//   * every spin has a wall-clock bound (s_memrealtime): on timeout the workgroup raises the plan's
-//     sticky abort flag and returns, so the grid always drains.
+//   GEMV    up to 4 planar weight matrices of one type against one activation vector x.  The prologue forms x in LDS --
+//           x0 | rms_norm(x0 + x1) * w | unary(x0) * x1, quantized exactly as the CPU does (act_quant.cuh) -- then the
+//           workgroup streams its rows; arithmetic per row is gemv_fast.hip's (gemv_stream.cuh is shared): bit-identical.
+//   ATTN    rope(q), rope(k), this token's K / V cache stores and causal attention of the one token over the f16 cache,
+//           one workgroup per (head, KV split); COMBINE merges the splits of a head (log-sum-exp).
 //
-// Arithmetic per row is EXACTLY gemv_fast.hip's (same chunk loaders / consumers, gemv_stream.cuh):
-// bit-identical outputs to mi355q_mul_mat for the same matrices.
+//   * DATAFLOW, not barriers.  A value produced during the run is published element by element as an 8-byte
+//     {f32 value, u32 tag} GRANULE (one naturally aligned agent-scope store; tag = launch epoch + producing stage) in a
+//     plan-private buffer; a consumer polls exactly the granules it needs with agent-scope (sc1) loads until every tag
+//     matches.  No counter, no flag, no release/acquire fence, no store acknowledgement: the hand-off is the data
+//     (MI355X_MICROARCH.md, hand-off price list: a data-tagged granule is the cheapest cross-CU edge; a flag/barrier
+//     protocol costs 1.7-2.5x).  Round 1's two-level grid barrier + separate activation fetch cost 8-9 us per dependent
+//     step; see DESIGN.md section 5.6 for the measured chain now.
+//   * the weight stream does not stop at a dependency: a wave requests the first chunks of its rows of stage s+1 as soon
+//     as it has finished stage s, BEFORE it polls for the activations.
+//   * no re-arming: tags grow monotonically over launches (the host re-zeroes the granules before the 32-bit epoch wraps).
+//   * every poll has a wall-clock bound (s_memrealtime): on timeout the workgroup raises the plan's sticky abort flag and
+//     returns, so the grid always drains (one workgroup per CU: all are resident unless another persistent kernel holds CUs).
 //
-// Bound: HBM read of W.  Algorithmic bytes per launch = sum over stages, matrices of m * row_size(type, k).
+// Bound: HBM read of W.  Algorithmic bytes per launch = sum over stages, matrices of m * row_size(type, k) (+ the KV cache
+// window of ATTN stages: 2 * n_kv * n_head_kv * head_dim * 2 bytes).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <vector>
 
 #include "gemv_stream.cuh"
@@ -36,26 +36,46 @@ constexpr int PLAN_D_MAX = 8;                     // ring depth (1-KiB steps in 
 __host__ __device__ constexpr int plan_depth(int type) {   // Q5_K / Q6_K slots carry qh too (1.5 KiB per step): 6 steps are the bytes of 8 Q4_K steps
     return (type == MI355Q_TYPE_Q5_K || type == MI355Q_TYPE_Q6_K) ? 6 : PLAN_D_MAX;
 }
-enum { PLAN_F_BARRIER = 1, PLAN_F_NEW_X = 2 };
-// Grid barrier state (u32 words; every counter on its own 128-byte line).  Two levels, so that no line is hammered
-// by more than ~32 agents: workgroup i belongs to group i % 8 (the dispatcher deals workgroups round-robin to the 8
-// XCDs, so a group is normally one XCD; nothing but speed depends on that).  Arrive = one atomic add on the group's
-// counter.  The group's leader (workgroup g) polls the 8 group counters with one 8-lane load and then publishes
-// release[g]; the other workgroups of the group poll only release[g].
-constexpr int PLAN_GROUPS = 8, PLAN_LINE = 32;
-enum { PLAN_SYNC_ARRIVE = 0, PLAN_SYNC_RELEASE = PLAN_GROUPS * PLAN_LINE, PLAN_SYNC_EXIT = 2 * PLAN_GROUPS * PLAN_LINE,
-       PLAN_SYNC_ABORT = PLAN_SYNC_EXIT + PLAN_LINE, PLAN_SYNC_WORDS = PLAN_SYNC_ABORT + PLAN_LINE };
+enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16 };
+enum { PLAN_K_GEMV = 0, PLAN_K_ATTN = 1, PLAN_K_COMBINE = 2 };
+enum { PLAN_SYNC_ABORT = 0, PLAN_SYNC_WORDS = 32 };
+
+typedef unsigned long long Granule;               // low dword: f32 value bits, high dword: tag
+
+// an operand vector: plain f32 (complete before the launch) or granules published by an earlier stage (tag_off = its index + 1)
+struct VecSrc { const float * plain; const Granule * gran; unsigned tag_off, pad; };
+
+struct AttnStage {
+    VecSrc q, k, v;
+    const int32_t * pos, * n_kv_dev;
+    const float * freq_factors;
+    const char * k_cache, * v_cache;
+    int64_t k_nb_pos, k_nb_head, v_nb_pos, v_nb_dim, v_nb_head, v_dst_nb;
+    char * const * k_dst, * const * v_dst;
+    const char * mask;
+    Granule * part;                                // [n_head][n_split][head_dim + 2]  (o, m, l) of every split
+    Granule * out_gran; float * out_plain;
+    int mask_f16, n_head, n_head_kv, hd, n_kv, n_split, per, plain;
+    float scale;
+    // rope (ggml_rope_cache_init; see ops_glue.hip k_rope)
+    int n_dims, neox; float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1;
+};
 
 struct alignas(64) PlanStage {
     // -- what the streamers need per row, contiguous (arrives with a few scalar loads issued together) --
     const uint8_t * w[GEMV_MAX_MATS];
     int64_t         w_stride[GEMV_MAX_MATS];
     float *         y[GEMV_MAX_MATS];
+    Granule *       yg;                           // granules of the stage's outputs, indexed by CONCATENATED row
     int             row_begin[GEMV_MAX_MATS];     // first concatenated row of each matrix (unused entries: INT_MAX)
     int             total_rows, rows_per_wg, k, n_mats;
     // -- the rest --
-    const float *   x;
-    int             type, flags, prime, pad;      // prime: ring slots requested before the barrier / quantization
+    int             type, flags, prime, kind;
+    VecSrc          x0, x1;
+    const float *   norm_w;
+    Granule *       sum_gran; float * sum_plain;
+    const AttnStage * attn;
+    float           eps; int x_kind, x_unary; unsigned tag_off;
 };
 typedef const __attribute__((address_space(4))) PlanStage * StageC;   // descriptors are read with scalar loads
 
@@ -79,18 +99,18 @@ __device__ int g_plan_stamp_stages = 0;
 #define PLAN_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ bool plan_type_is_q8k(int t) { return t == MI355Q_TYPE_Q4_K || t == MI355Q_TYPE_Q5_K || t == MI355Q_TYPE_Q6_K; }
-
 // A wave's own copy of the per-matrix fields of a stage descriptor, in SGPRs: read once per stage with independent
 // scalar loads (one round trip).  Reading them per row instead (matrix index -> base -> stride: a dependent chain of
 // scalar loads) costs microseconds whenever the descriptors miss the scalar cache.
 struct StageW {
-    const uint8_t * w0, * w1, * w2, * w3; int64_t ws0, ws1, ws2, ws3; float * y0, * y1, * y2, * y3; int rb1, rb2, rb3;
-    __device__ __forceinline__ void load(StageC st) {
+    const uint8_t * w0, * w1, * w2, * w3; int64_t ws0, ws1, ws2, ws3; float * y0, * y1, * y2, * y3; Granule * g; int rb1, rb2, rb3;
+    __device__ __forceinline__ void load(StageC st) {          // what the loader needs (live through the prologue)
         w0 = st->w[0]; w1 = st->w[1]; w2 = st->w[2]; w3 = st->w[3];
         ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = st->w_stride[2]; ws3 = st->w_stride[3];
-        y0 = st->y[0]; y1 = st->y[1]; y2 = st->y[2]; y3 = st->y[3];
         rb1 = st->row_begin[1]; rb2 = st->row_begin[2]; rb3 = st->row_begin[3];
+    }
+    __device__ __forceinline__ void load_out(StageC st) {      // what the consumer needs (read after the prologue)
+        y0 = st->y[0]; y1 = st->y[1]; y2 = st->y[2]; y3 = st->y[3]; g = st->yg;
     }
     // all fields are read BEFORE the selects (a select between field addresses would keep the struct in scratch memory)
     __device__ __forceinline__ const uint8_t * row_ptr(int r) const {
@@ -137,11 +157,16 @@ __device__ __forceinline__ void plan_fill(Chunk (&ring)[D], int from, int to, Pl
     for (int d = 0; d < D; ++d) if (d >= from && d < to) plan_issue<T>(ring[d], ld, st, g, lane);
 }
 
+__device__ __forceinline__ void publish(Granule * gp, float v, unsigned tag) {
+    __hip_atomic_store(gp, ((Granule) tag << 32) | (Granule) __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // consume this wave's rows of the stage; slot d holds item d, d+D, ... ; refills keep D items in flight
 template <int T, int D>
-__device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, const StageW & st, const StageGeom & g, int r_lo, int wave, int lane, const ActView * av) {
+__device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, const StageW & st, const StageGeom & g, int r_lo, int wave, int lane,
+                                         const ActView * av, unsigned tag, bool plain) {
     // the consumers' lane-invariant state (LDS offsets, shifts) is derived from an opaque copy of the lane id HERE, so
-    // that it cannot be computed (and kept live, and spilled) before the barrier / quantization phase
+    // that it cannot be computed (and kept live, and spilled) before the prologue
     int lane_c = lane; asm volatile("" : "+v"(lane_c));
     int cs_gr = r_lo + wave, cs_s = 0;
     float acc[1] = { 0.0f };
@@ -150,24 +175,18 @@ __device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, cons
         for (int d = 0; d < D; ++d) {
             if (cs_gr < g.r_hi) {                             // wave-uniform
                 if (64 * cs_s + lane_c < g.nchunks) Consume<T, 1>::run(ring[d], cs_s, lane_c, av, acc);
-                if (++cs_s == g.steps) {                      // row finished: reduce, store (agent-coherent), next row
+                if (++cs_s == g.steps) {                      // row finished: reduce, publish (one granule), next row
                     const float t = wave_sum(acc[0]);
-                    if (lane_c == 0) __hip_atomic_store(st.y_ptr(cs_gr), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane_c == 0) {
+                        publish(st.g + cs_gr, t, tag);
+                        if (plain) *st.y_ptr(cs_gr) = t;
+                    }
                     acc[0] = 0.0f; cs_s = 0; cs_gr += GEMV_WAVES;
                 }
                 plan_issue<T>(ring[d], ld, st, g, lane);      // refill the slot just consumed
             }
         }
     }
-}
-
-// ---- activations: agent-coherent fetch (another XCD wrote them in this same launch) -------------
-// Buffer loads with the sc1 (agent scope) cache policy: 16 bytes per lane, tracked by the compiler's vmcnt bookkeeping
-// (so weight loads issued AFTER them can stay in flight while they are waited for), and out-of-range lanes read 0.
-typedef unsigned int plan_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 plan_act_fetch(__amdgpu_buffer_rsrc_t xr, int span, int lane) {
-    const plan_u4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, span * 1024 + 16 * lane, 0, 16 /* sc1 */);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 // LDS visibility + workgroup barrier WITHOUT draining vmcnt: __syncthreads() fences every address space and so waits
@@ -179,56 +198,152 @@ __device__ __forceinline__ void plan_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// ---- operand gather ------------------------------------------------------------------------------------------------
+// A CHUNK is 128 consecutive elements of a vector; lane l owns elements 128c + 2l, +1.  Granules: one 16-byte agent-scope
+// (sc1) buffer load per lane = {v0, tag0, v1, tag1}; plain vectors: one 8-byte load.  Lanes beyond the vector read zeros
+// (the buffer resource bounds the access) and are excluded from the tag check.
+typedef unsigned int plan_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int plan_u2 __attribute__((ext_vector_type(2)));
+struct SrcView { __amdgpu_buffer_rsrc_t rs; unsigned expect; int tagged; };
+__device__ __forceinline__ SrcView src_view(const VecSrc & v, int first, int n, unsigned epoch) {
+    SrcView s;
+    s.tagged = v.gran != nullptr;
+    s.expect = epoch + v.tag_off;
+    if (s.tagged) s.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (v.gran + first), 0, n * 8, 0x00020000);
+    else          s.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (v.plain + first), 0, n * 4, 0x00020000);
+    return s;
+}
+// one attempt: returns the two values and whether they are valid (tags match)
+__device__ __forceinline__ bool src_try(const SrcView & s, int chunk, int lane, float & a0, float & a1) {
+    if (s.tagged) {
+        const plan_u4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, chunk * 1024 + 16 * lane, 0, 16 /* sc1 */);
+        a0 = __uint_as_float(v.x); a1 = __uint_as_float(v.z);
+        return v.y == s.expect && v.w == s.expect;
+    }
+    const plan_u2 v = __builtin_amdgcn_raw_buffer_load_b64(s.rs, chunk * 512 + 8 * lane, 0, 0);
+    a0 = __uint_as_float(v.x); a1 = __uint_as_float(v.y);
+    return true;
+}
+
+struct PollCtx { unsigned * sync; unsigned long long timeout, t0; };
+// false = give up (timeout or the plan's abort flag is up)
+__device__ __forceinline__ bool poll_backoff(const PollCtx & pc, unsigned & spins, int lane) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) == 0u) {
+        unsigned ab = 0;
+        if (lane == 0) ab = __hip_atomic_load(pc.sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab = (unsigned) __builtin_amdgcn_readfirstlane((int) ab);
+        if (ab != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - pc.t0 > pc.timeout) {
+            if (lane == 0) __hip_atomic_store(pc.sync + PLAN_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+// f64 sum over the 64 lanes on DPP (no LDS crossbar), result uniform
+__device__ __forceinline__ double dpp_d(double v, int which) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int) b, hi = (int) (b >> 32);
+    switch (which) {
+    case 0: lo = dpp_i<0xB1>(lo);  hi = dpp_i<0xB1>(hi);  break;
+    case 1: lo = dpp_i<0x4E>(lo);  hi = dpp_i<0x4E>(hi);  break;
+    case 2: lo = dpp_i<0x141>(lo); hi = dpp_i<0x141>(hi); break;
+    default: lo = dpp_i<0x140>(lo); hi = dpp_i<0x140>(hi); break;
+    }
+    return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int) b, l), hi = __builtin_amdgcn_readlane((int) (b >> 32), l);
+    return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_d(v, 0); v += dpp_d(v, 1); v += dpp_d(v, 2); v += dpp_d(v, 3);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+
+__device__ __forceinline__ float unary_f(int uop, float x) {          // ops_glue.hip k_unary_mul, same expressions
+    if (uop == MI355Q_UNARY_SILU) return __fdiv_rn(x, 1.0f + expf(-x));
+    if (uop == MI355Q_UNARY_RELU) return x > 0.0f ? x : 0.0f;
+    return __fdiv_rn(1.0f, 1.0f + expf(-x));
+}
+
+struct StageCtx {
+    uint8_t * lds; float * stg; int * ctl; double * part; unsigned * sync; unsigned long long timeout;
+    unsigned grid, epoch; int even, stage;
+};
+enum { CTL_OK = 0 };
+
+// Gather the stage's activation vector t[k] (f32) into the LDS staging area: PLAIN t = x0, NORM t = x0 (+ x1), UNARY_MUL
+// t = unary(x0) * x1.  Chunks are dealt round-robin to the waves, two in flight per wave.  NORM: returns this wave's partial
+// sum of squares in `ssq`; the workgroup `sum_wg` also publishes t (the next residual's operand).  false = poll gave up.
+__device__ __forceinline__ bool plan_gather(StageC st, const StageCtx & c, int k, int wave, int lane, double & ssq) {
+    const int x_kind = st->x_kind, uop = st->x_unary;
+    const bool two = st->x1.plain != nullptr || st->x1.gran != nullptr;
+    VecSrc v0, v1;
+    v0.plain = st->x0.plain; v0.gran = st->x0.gran; v0.tag_off = st->x0.tag_off; v0.pad = 0;
+    v1.plain = st->x1.plain; v1.gran = st->x1.gran; v1.tag_off = st->x1.tag_off; v1.pad = 0;
+    const SrcView s0 = src_view(v0, 0, k, c.epoch);
+    const SrcView s1 = src_view(two ? v1 : v0, 0, k, c.epoch);
+    const bool pub = (st->flags & PLAN_F_SUM) && blockIdx.x == (unsigned) c.stage % c.grid;
+    const unsigned tag = c.epoch + st->tag_off;
+    const int chunks = (k + 127) >> 7;
+    PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    ssq = 0.0;
+#pragma unroll 1
+    for (int ch = wave; ch < chunks; ch += 2 * GEMV_WAVES) {
+        const int ch2 = ch + GEMV_WAVES;                       // second chunk of the pair (may be past the end: reads zeros, not checked)
+        float a0, a1, b0 = 0.f, b1 = 0.f, e0, e1, f0 = 0.f, f1 = 0.f;
+        for (;;) {
+            bool ok = src_try(s0, ch, lane, a0, a1) || 128 * ch + 2 * lane >= k;
+            bool ok2 = src_try(s0, ch2, lane, e0, e1) || 128 * ch2 + 2 * lane >= k;
+            if (two) {
+                ok  = (src_try(s1, ch, lane, b0, b1)  || 128 * ch + 2 * lane >= k) && ok;
+                ok2 = (src_try(s1, ch2, lane, f0, f1) || 128 * ch2 + 2 * lane >= k) && ok2;
+            }
+            if (__ballot(!(ok && ok2)) == 0ull) break;
+            if (!poll_backoff(pc, spins, lane)) return false;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = h ? ch2 : ch;
+            const int e = 128 * cc + 2 * lane;
+            if (e < k) {                                       // (k is even)
+                const float p0 = h ? e0 : a0, p1 = h ? e1 : a1, q0 = h ? f0 : b0, q1 = h ? f1 : b1;
+                float t0, t1;
+                if (x_kind == MI355Q_X_UNARY_MUL) { t0 = __fmul_rn(unary_f(uop, p0), q0); t1 = __fmul_rn(unary_f(uop, p1), q1); }
+                else if (two)                     { t0 = __fadd_rn(p0, q0); t1 = __fadd_rn(p1, q1); }
+                else                              { t0 = p0; t1 = p1; }
+                if (x_kind == MI355Q_X_NORM) {
+                    ssq += (double) __fmul_rn(t0, t0); ssq += (double) __fmul_rn(t1, t1);      // (ggml_float)(x*x): the square is rounded to f32 first
+                    if (pub) {
+                        publish(st->sum_gran + e, t0, tag); publish(st->sum_gran + e + 1, t1, tag);
+                        if (st->flags & PLAN_F_SUM_PLAIN) { st->sum_plain[e] = t0; st->sum_plain[e + 1] = t1; }
+                    }
+                }
+                *(float2 *) (c.stg + e) = make_float2(t0, t1);
+            }
+        }
+    }
+    return true;
+}
+
 template <int FAM>
 __device__ __forceinline__ void plan_quantize_span(const float4 v, int span, uint8_t * lds, int k, bool even, int lane) {
-    if (span * 256 >= k) return;                               // wave-uniform
     if constexpr (FAM == FAM_Q8K) quantize_span_to_lds<FAM_Q8K, false>(v, span, lds, k, lane);
     else if (even)                quantize_span_to_lds<FAM_Q80, true>(v, span, lds, k, lane);
     else                          quantize_span_to_lds<FAM_Q80, false>(v, span, lds, k, lane);
 }
 
-// Called by wave 0 (all 64 lanes) of a workgroup: wait until every workgroup has arrived `arrivals` times.
-// false on timeout / abort.
-__device__ __forceinline__ bool plan_grid_wait(unsigned * sync, unsigned arrivals, unsigned grid, unsigned long long timeout_ticks, int lane) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned g = blockIdx.x % PLAN_GROUPS;
-    const bool leader = blockIdx.x < PLAN_GROUPS;
-    // leader: lane l < 8 watches group l (target = arrivals * size of group l); follower: lane 0 watches release[g]
-    const unsigned l = (unsigned) lane < (unsigned) PLAN_GROUPS ? (unsigned) lane : 0u;
-    const unsigned gsize = grid > l ? (grid - l + PLAN_GROUPS - 1) / PLAN_GROUPS : 0u;
-    const unsigned * addr = leader ? sync + PLAN_SYNC_ARRIVE + l * PLAN_LINE : sync + PLAN_SYNC_RELEASE + g * PLAN_LINE;
-    const unsigned target = leader ? arrivals * gsize : arrivals;
-    const bool watch = leader ? lane < PLAN_GROUPS : lane == 0;
-    unsigned spins = 0;
-    for (;;) {
-        unsigned v = target;
-        if (watch) v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot(v < target) == 0ull) break;
-        if ((++spins & 31u) == 0u) {
-            unsigned ab = 0;
-            if (lane == 0) ab = __hip_atomic_load(sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ab = (unsigned) __builtin_amdgcn_readfirstlane((int) ab);
-            if (ab != 0u) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
-                if (lane == 0) __hip_atomic_store(sync + PLAN_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-    if (leader && lane == 0) __hip_atomic_store(sync + PLAN_SYNC_RELEASE + g * PLAN_LINE, arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
-}
-
-// One stage, start to finish, for weight type T.  Deliberately NOT inlined: each type's streamer gets its own
-// register allocation (inlined side by side, the lane-invariant state of both types stays live and spills).
-//   prime (weights in flight) -> [grid barrier] -> [quantize x -> LDS] -> stream rows -> [acknowledge y, arrive]
-struct StageCtx {
-    uint8_t * lds; uint8_t * stage_lds; int * ctl; unsigned * sync; unsigned long long timeout;
-    unsigned grid, arrivals; int even, next_barrier, stage;
-};
-enum { CTL_OK = 0, CTL_WAVES = 1 };
-
+// One GEMV stage, start to finish, for weight type T:
+//   prime (weights in flight) -> [gather x (polls its producers) -> glue -> quantize x -> LDS] -> stream rows, publishing every y
 template <int T>
 static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c) {
     // an opaque copy of the lane id per stage: everything derived from it is recomputed here (a few VALU ops) instead
@@ -250,109 +365,354 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     plan_fill<T, PLAN_D>(ring, 0, st->prime, ld, sw, g, lane);                 // weights start flowing before anything else
     PLAN_STAMP(1);
 
-    if (flags & PLAN_F_BARRIER) {                             // every workgroup has finished (and made visible) all earlier stages
-        if (wave == 0) {
-            const bool ok = plan_grid_wait(c.sync, c.arrivals, c.grid, c.timeout, lane);
-            if (lane == 0) c.ctl[CTL_OK] = ok ? 1 : 0;
+    if (flags & PLAN_F_NEW_X) {
+        constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? FAM_Q80 : FAM_Q8K;
+        plan_lds_barrier();                                   // all waves are done with the previous LDS image and staging area
+        double ssq;
+        const bool ok = plan_gather(st, c, k, wave, lane, ssq);
+        if (!ok && lane == 0) c.ctl[CTL_OK] = 0;
+        PLAN_STAMP(2);
+        const int x_kind = st->x_kind;
+        if (x_kind == MI355Q_X_NORM) {
+            ssq = wave_sum_f64(ssq);
+            if (lane == 0) c.part[wave] = ssq;
         }
         plan_lds_barrier();
         if (!c.ctl[CTL_OK]) return false;
-    } else if (flags & PLAN_F_NEW_X) {
-        plan_lds_barrier();                                   // all waves are done with the previous LDS image
-    }
-    PLAN_STAMP(2);
-    if (flags & PLAN_F_NEW_X) {
-        // Spans of 256 activations are dealt round-robin to the waves, four in flight per wave (one memory round trip for
-        // k <= 16384).  Agent-scope (sc1) buffer loads: another XCD wrote them during this launch; lanes beyond k read 0.
-        constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? FAM_Q80 : FAM_Q8K;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *) st->x, 0, k * 4, 0x00020000);
-        const int spans = (k + 255) >> 8;
-        // The raw f32 spans are parked in a per-wave LDS staging area right after they arrive: holding them in VGPRs
-        // through the quantizer (on top of the ring) does not fit 128 registers.
-        float4 * stg = (float4 *) (c.stage_lds + wave * (4 * 1024)) + lane;
-        auto quantize4 = [&](int span0) {
-#pragma unroll 1
-            for (int i = 0; i < 4; ++i) {                      // same-lane round trip through LDS: no barrier needed
-                const float4 v = stg[64 * i];
-                plan_quantize_span<FAM>(v, span0 + i * GEMV_WAVES, c.lds, k, c.even != 0, lane);
-            }
-        };
-        {   // first pass (all of k <= 16384)
-            const float4 x0 = plan_act_fetch(xr, wave, lane), x1 = plan_act_fetch(xr, wave + GEMV_WAVES, lane);
-            const float4 x2 = plan_act_fetch(xr, wave + 2 * GEMV_WAVES, lane), x3 = plan_act_fetch(xr, wave + 3 * GEMV_WAVES, lane);
-            stg[0] = x0; stg[64] = x1; stg[128] = x2; stg[192] = x3;
+        float scale = 1.0f;
+        const float * nw = nullptr;
+        if (x_kind == MI355Q_X_NORM) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < GEMV_WAVES; i += 4) s += (c.part[i] + c.part[i + 1]) + (c.part[i + 2] + c.part[i + 3]);
+            const float mean = (float) (s / (double) k);
+            const float root = (float) sqrt((double) __fadd_rn(mean, st->eps));      // both roundings of the CPU (ops_glue.hip k_add_rms_norm_mul)
+            scale = (float) (1.0 / (double) root);
+            nw = st->norm_w;
         }
-        quantize4(wave);
+        const int spans = (k + 255) >> 8;
 #pragma unroll 1
-        for (int span = wave + 4 * GEMV_WAVES; span < spans; span += 4 * GEMV_WAVES) {
-            const float4 x0 = plan_act_fetch(xr, span, lane), x1 = plan_act_fetch(xr, span + GEMV_WAVES, lane);
-            const float4 x2 = plan_act_fetch(xr, span + 2 * GEMV_WAVES, lane), x3 = plan_act_fetch(xr, span + 3 * GEMV_WAVES, lane);
-            stg[0] = x0; stg[64] = x1; stg[128] = x2; stg[192] = x3;
-            quantize4(span);
+        for (int span = wave; span < spans; span += GEMV_WAVES) {
+            const int e = span * 256 + 4 * lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < k) {
+                v = *(const float4 *) (c.stg + e);
+                if (x_kind == MI355Q_X_NORM) {
+                    v.x = __fmul_rn(v.x, scale); v.y = __fmul_rn(v.y, scale); v.z = __fmul_rn(v.z, scale); v.w = __fmul_rn(v.w, scale);
+                    if (nw) { const float4 ww = *(const float4 *) (nw + e); v.x = __fmul_rn(v.x, ww.x); v.y = __fmul_rn(v.y, ww.y); v.z = __fmul_rn(v.z, ww.z); v.w = __fmul_rn(v.w, ww.w); }
+                }
+            }
+            plan_quantize_span<FAM>(v, span, c.lds, k, c.even != 0, lane);
         }
         plan_lds_barrier();
     }
     plan_fill<T, PLAN_D>(ring, st->prime, PLAN_D, ld, sw, g, lane);                // top the ring up (a no-op when prime == depth)
+    sw.load_out(st);
     PLAN_STAMP(3);
     ActView av[1];
     av[0].base = c.lds; av[0].k = k;
-    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av);
+    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av, c.epoch + st->tag_off, (flags & PLAN_F_PLAIN_Y) != 0);
     PLAN_STAMP(4);
+    return true;
+}
 
-    if (c.next_barrier) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's y stores have reached the coherence point (its ring is empty)
-        PLAN_STAMP(5);
-        if (lane == 0) {                                      // the last of the 16 waves arrives for the workgroup; nobody waits here
-            const int done = atomicAdd(&c.ctl[CTL_WAVES], 1) + 1;
-            if (done == GEMV_WAVES * (int) (c.arrivals + 1))
-                __hip_atomic_fetch_add(c.sync + PLAN_SYNC_ARRIVE + (blockIdx.x % PLAN_GROUPS) * PLAN_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- attention of one token ------------------------------------------------------------------------------------------
+// Workgroup b = (head h, KV split sp).  LDS (inside the staging area): sq / sk / sv f32 [hd], kh / vh f16 [hd] (this token's
+// cache row, rounded as stored), sc f32 [per] (scores, then probabilities), red f32 [16][hd] (P V partials), maxs / sums [16].
+__device__ __forceinline__ float rope_theta(const AttnStage * a, int pos, int ip, float & mscale) {
+    const float ff = a->freq_factors ? a->freq_factors[ip] : 1.0f;
+    float th = (float) pos;
+    for (int j = 0; j < ip; ++j) th = __fmul_rn(th, a->theta_scale);          // repeated f32 multiplication, as ggml_rope_cache_init does
+    const float theta_extrap = __fdiv_rn(th, ff);
+    const float theta_interp = a->freq_scale * theta_extrap;
+    float theta = theta_interp; mscale = a->attn_factor;
+    if (a->ext_factor != 0.0f) {
+        const float y = ((float) ip - a->corr0) / fmaxf(0.001f, a->corr1 - a->corr0);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * a->ext_factor;
+        theta = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / a->freq_scale);
+    }
+    return theta;
+}
+
+static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCtx & c, unsigned tag) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int tid = (int) threadIdx.x;
+    const int hd = a->hd, n_split = a->n_split;
+    if ((int) blockIdx.x >= a->n_head * n_split) return true;                    // (uniform: the whole workgroup has nothing to do)
+    const int h = (int) blockIdx.x / n_split, sp = (int) blockIdx.x % n_split, gq = a->n_head / a->n_head_kv, g = h / gq;
+    float * sq = c.stg, * sk = sq + hd, * sv = sk + hd;
+    __half * kh = (__half *) (sv + hd), * vh = kh + hd;
+    float * maxs = (float *) (vh + hd), * sums = maxs + GEMV_WAVES;
+    float * red = sums + GEMV_WAVES;                                          // [16][hd]
+    float * sc = red + GEMV_WAVES * hd;                                        // [per]
+    plan_lds_barrier();                                                        // the staging area is free (previous stage's quantizer is done)
+
+    // 1. q head h, k / v head g  (hd <= 256: at most two 128-element chunks each)
+    {
+        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        const int nch = (hd + 127) >> 7;
+        bool ok_all = true;
+        for (int item = wave; item < 3 * nch; item += GEMV_WAVES) {
+            const int which = item / nch, ch = item % nch;
+            const VecSrc & vs = which == 0 ? a->q : which == 1 ? a->k : a->v;
+            const SrcView s = src_view(vs, (which == 0 ? h : g) * hd, hd, c.epoch);
+            float * dst = which == 0 ? sq : which == 1 ? sk : sv;
+            float v0, v1;
+            for (;;) {
+                const bool ok = src_try(s, ch, lane, v0, v1) || 128 * ch + 2 * lane >= hd;
+                if (__ballot(!ok) == 0ull) break;
+                if (!poll_backoff(pc, spins, lane)) { ok_all = false; break; }
+            }
+            if (!ok_all) break;
+            const int e = 128 * ch + 2 * lane;
+            if (e < hd) { dst[e] = v0; dst[e + 1] = v1; }
         }
+        if (!ok_all && lane == 0) c.ctl[CTL_OK] = 0;
+    }
+    plan_lds_barrier();
+    if (!c.ctl[CTL_OK]) return false;
+
+    // 2. rope (ops_glue.hip k_rope / ggml-cpu/ops.cpp:5088-5270); q is then rounded to f16 as the CPU's f16 vec_dot does with src1,
+    //    k and v to f16 as the cache stores them.  One rotated pair per thread: pairs of q first, then of k.
+    const int pos = a->pos[0];
+    const int half = hd >> 1;
+    if (tid < 2 * half) {
+        float * x = tid < half ? sq : sk;
+        const int ip = tid < half ? tid : tid - half;
+        const int i0 = 2 * ip;
+        float r0, r1; int e0, e1;
+        if (i0 < a->n_dims) {
+            float mscale;
+            const float theta = rope_theta(a, pos, ip, mscale);
+            const float cs = cosf(theta) * mscale, sn = sinf(theta) * mscale;
+            e0 = a->neox ? ip : i0; e1 = a->neox ? ip + a->n_dims / 2 : i0 + 1;
+            const float x0 = x[e0], x1 = x[e1];
+            r0 = x0 * cs - x1 * sn; r1 = x0 * sn + x1 * cs;
+        } else { e0 = i0; e1 = i0 + 1; r0 = x[e0]; r1 = x[e1]; }
+        // (every pair reads and writes only its own two elements: in place is safe)
+        if (tid < half) { x[e0] = __half2float(__float2half_rn(r0)); x[e1] = __half2float(__float2half_rn(r1)); }
+        else            { kh[e0] = __float2half_rn(r0); kh[e1] = __float2half_rn(r1); }
+    } else if (tid < 2 * half + hd) {
+        const int d = tid - 2 * half;
+        vh[d] = __float2half_rn(sv[d]);
+    }
+    plan_lds_barrier();
+    char * const kdst = *a->k_dst, * const vdst = *a->v_dst;
+    if (sp == 0 && h % gq == 0 && tid < hd) {                                   // this token's cache row: one workgroup per kv head stores it
+        ((__half *) kdst)[g * hd + tid] = kh[tid];
+        *(__half *) (vdst + (int64_t) (g * hd + tid) * a->v_dst_nb) = vh[tid];
+    }
+    const int slot = (int) ((kdst - a->k_cache) / a->k_nb_pos);              // the position whose row is being stored right now: read from LDS
+
+    // 3. scores of this split's positions: one wave per position, a lane owns dims (2l, 2l+1) [+128]
+    int n_kv = a->n_kv;                                                        // the window of THIS run (the plan is sized for a->n_kv)
+    if (a->n_kv_dev) n_kv = min(n_kv, max(1, a->n_kv_dev[0]));
+    const int per = (n_kv + n_split - 1) / n_split;
+    const int j0 = sp * per, j1 = min(n_kv, j0 + per), cnt = max(0, j1 - j0);
+    const char * kbase = a->k_cache + (int64_t) g * a->k_nb_head;
+    const float q0 = 2 * lane < hd ? sq[2 * lane] : 0.f, q1 = 2 * lane < hd ? sq[2 * lane + 1] : 0.f;
+    const float q2 = 2 * lane + 128 < hd ? sq[2 * lane + 128] : 0.f, q3 = 2 * lane + 128 < hd ? sq[2 * lane + 129] : 0.f;
+#pragma unroll 1
+    for (int jb = wave; jb < cnt; jb += 4 * GEMV_WAVES) {
+        __half2 kv[4], kw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + jb + u * GEMV_WAVES;
+            kv[u] = __half2(); kw[u] = __half2();
+            if (jb + u * GEMV_WAVES < cnt) {
+                if (j == slot) { if (2 * lane < hd) kv[u] = *(const __half2 *) (kh + 2 * lane); if (2 * lane + 128 < hd) kw[u] = *(const __half2 *) (kh + 2 * lane + 128); }
+                else {
+                    const char * row = kbase + (int64_t) j * a->k_nb_pos;
+                    if (2 * lane < hd) kv[u] = *(const __half2 *) (row + 4 * lane);
+                    if (2 * lane + 128 < hd) kw[u] = *(const __half2 *) (row + 4 * lane + 256);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jb + u * GEMV_WAVES < cnt) {
+                const float2 f = __half22float2(kv[u]), f2 = __half22float2(kw[u]);
+                float d = q0 * f.x + q1 * f.y + q2 * f2.x + q3 * f2.y;
+                d = wave_sum(d);
+                const int j = j0 + jb + u * GEMV_WAVES;
+                float m = 0.0f;
+                if (a->mask) m = a->mask_f16 ? __half2float(((const __half *) a->mask)[j]) : ((const float *) a->mask)[j];
+                // (a fully masked position stays -inf whatever its cache row holds: never-written rows may be anything, 0 * NaN included)
+                if (lane == 0) sc[jb + u * GEMV_WAVES] = m == -INFINITY ? -INFINITY : __fadd_rn(__fmul_rn(d, a->scale), m);
+            }
+        }
+    }
+    plan_lds_barrier();
+    // 4. local softmax statistics
+    float mx = -INFINITY;
+    for (int j = tid; j < cnt; j += GEMV_THREADS) mx = fmaxf(mx, sc[j]);
+    mx = wave_max_f(mx);
+    if (lane == 0) maxs[wave] = mx;
+    plan_lds_barrier();
+    mx = maxs[0];
+#pragma unroll
+    for (int i = 1; i < GEMV_WAVES; ++i) mx = fmaxf(mx, maxs[i]);
+    float ls = 0.0f;
+    for (int j = tid; j < cnt; j += GEMV_THREADS) {
+        const float p = mx == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx));
+        sc[j] = p; ls += p;
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) sums[wave] = ls;
+    plan_lds_barrier();
+    float l = 0.0f;
+#pragma unroll
+    for (int i = 0; i < GEMV_WAVES; ++i) l += sums[i];
+    // 5. o[d] = sum_j p_j v[j][d]   (positions with p == 0 are skipped: masked cache rows may hold anything)
+    const char * vbase = a->v_cache + (int64_t) g * a->v_nb_head;
+    if (a->v_nb_dim == 2) {
+        // rows per position (the -fa layout): a wave takes positions jb = wave, wave+16, ...; a lane owns dims (2l, 2l+1) [+128]
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 1
+        for (int jb = wave; jb < cnt; jb += 4 * GEMV_WAVES) {
+            __half2 vv[4], vw[4]; float p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = jb + u * GEMV_WAVES, j = j0 + jj;
+                vv[u] = __half2(); vw[u] = __half2(); p[u] = jj < cnt ? sc[jj] : 0.0f;
+                if (p[u] != 0.0f) {
+                    if (j == slot) { if (2 * lane < hd) vv[u] = *(const __half2 *) (vh + 2 * lane); if (2 * lane + 128 < hd) vw[u] = *(const __half2 *) (vh + 2 * lane + 128); }
+                    else {
+                        const char * row = vbase + (int64_t) j * a->v_nb_pos;
+                        if (2 * lane < hd) vv[u] = *(const __half2 *) (row + 4 * lane);
+                        if (2 * lane + 128 < hd) vw[u] = *(const __half2 *) (row + 4 * lane + 256);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2 f = __half22float2(vv[u]), f2 = __half22float2(vw[u]);
+                o0 += p[u] * f.x; o1 += p[u] * f.y; o2 += p[u] * f2.x; o3 += p[u] * f2.y;
+            }
+        }
+        if (2 * lane < hd) { red[wave * hd + 2 * lane] = o0; red[wave * hd + 2 * lane + 1] = o1; }
+        if (2 * lane + 128 < hd) { red[wave * hd + 2 * lane + 128] = o2; red[wave * hd + 2 * lane + 129] = o3; }
+        plan_lds_barrier();
+        if (tid < hd) {
+            float o = 0.0f;
+#pragma unroll
+            for (int i = 0; i < GEMV_WAVES; ++i) o += red[i * hd + tid];
+            red[tid] = o;                                                      // (row 0 of red now holds o; every thread touches only its column)
+        }
+    } else {
+        // transposed cache (positions contiguous per dim): a wave takes dims d = wave, wave+16, ...; lanes run over the positions
+#pragma unroll 1
+        for (int d = wave; d < hd; d += GEMV_WAVES) {
+            const char * col = vbase + (int64_t) d * a->v_nb_dim;
+            float o = 0.0f;
+            for (int jj = lane; jj < cnt; jj += 64) {
+                const float p = sc[jj];
+                if (p != 0.0f) {
+                    const int j = j0 + jj;
+                    const float v = j == slot ? __half2float(vh[d]) : __half2float(*(const __half *) (col + (int64_t) j * a->v_nb_pos));
+                    o += p * v;
+                }
+            }
+            o = wave_sum(o);
+            if (lane == 0) red[d] = o;
+        }
+    }
+    plan_lds_barrier();
+    // 6. publish (o, m, l) of this split
+    Granule * part = a->part + (size_t) ((size_t) h * n_split + sp) * (hd + 2);
+    if (tid < hd) publish(part + tid, red[tid], tag);
+    else if (tid == hd) publish(part + hd, mx, tag);
+    else if (tid == hd + 1) publish(part + hd + 1, l, tag);
+    return true;
+}
+
+// merge the KV splits of a head: out = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s     (workgroup h * n_split does head h)
+static __device__ __noinline__ bool plan_attn_combine(const AttnStage * a, const StageCtx & c, unsigned tag) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int tid = (int) threadIdx.x;
+    const int hd = a->hd, n_split = a->n_split;
+    if ((int) blockIdx.x >= a->n_head * n_split || (int) blockIdx.x % n_split != 0) return true;
+    const int h = (int) blockIdx.x / n_split;
+    const int n = n_split * (hd + 2);
+    float * buf = c.stg;
+    plan_lds_barrier();
+    {
+        VecSrc vs; vs.plain = nullptr; vs.gran = a->part + (size_t) h * n; vs.tag_off = 0; vs.pad = 0;
+        SrcView s = src_view(vs, 0, n, 0); s.expect = tag - 1;                  // the partials carry the ATTN stage's tag (the stage before this one)
+        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        bool ok_all = true;
+        for (int ch = wave; ch < ((n + 127) >> 7); ch += GEMV_WAVES) {
+            float v0, v1;
+            for (;;) {
+                const bool ok = src_try(s, ch, lane, v0, v1) || 128 * ch + 2 * lane >= n;
+                if (__ballot(!ok) == 0ull) break;
+                if (!poll_backoff(pc, spins, lane)) { ok_all = false; break; }
+            }
+            if (!ok_all) break;
+            const int e = 128 * ch + 2 * lane;
+            if (e < n) { buf[e] = v0; buf[e + 1] = v1; }
+        }
+        if (!ok_all && lane == 0) c.ctl[CTL_OK] = 0;
+    }
+    plan_lds_barrier();
+    if (!c.ctl[CTL_OK]) return false;
+    if (tid < hd) {
+        float M = -INFINITY;
+        for (int s = 0; s < n_split; ++s) M = fmaxf(M, buf[s * (hd + 2) + hd]);
+        float L = 0.0f, o = 0.0f;
+        for (int s = 0; s < n_split; ++s) {
+            const float m = buf[s * (hd + 2) + hd];
+            const float w = m == -INFINITY ? 0.0f : expf(__fsub_rn(m, M));
+            L += w * buf[s * (hd + 2) + hd + 1];
+            o += w * buf[s * (hd + 2) + tid];
+        }
+        const float r = __fdiv_rn(o, L);
+        publish(a->out_gran + h * hd + tid, r, tag);
+        if (a->plain) a->out_plain[h * hd + tid] = r;
     }
     return true;
 }
 
 template <unsigned SET>
 __global__ void __launch_bounds__(GEMV_THREADS)
-k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsigned long long timeout_ticks, int lds_image_bytes) {
+k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsigned long long timeout_ticks, int lds_image_bytes, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     StageC stages = (StageC) stages_g;
     if (__hip_atomic_load(sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // sticky: a plan that timed out stays dead
 
     StageCtx c;
-    c.lds = lds; c.ctl = (int *) (lds + lds_image_bytes); c.stage_lds = lds + lds_image_bytes + 64; c.sync = sync; c.timeout = timeout_ticks;
-    c.grid = gridDim.x; c.arrivals = 0; c.even = even;
-    if (threadIdx.x == 0) { c.ctl[CTL_OK] = 1; c.ctl[CTL_WAVES] = 0; }
+    c.lds = lds; c.ctl = (int *) (lds + lds_image_bytes); c.part = (double *) (lds + lds_image_bytes + 64);
+    c.stg = (float *) (lds + lds_image_bytes + 64 + 8 * GEMV_WAVES);
+    c.sync = sync; c.timeout = timeout_ticks; c.grid = gridDim.x; c.even = even; c.epoch = epoch;
+    if (threadIdx.x == 0) c.ctl[CTL_OK] = 1;
     plan_lds_barrier();
 
 #pragma unroll 1
     for (int s = 0; s < n_stages; ++s) {
         StageC st = stages + s;
         c.stage = s;
-        c.next_barrier = (s + 1 < n_stages && ((st + 1)->flags & PLAN_F_BARRIER)) ? 1 : 0;
         bool ok = true;
-        switch (st->type) {
-        case MI355Q_TYPE_Q4_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_K>(st, c); break;
-        case MI355Q_TYPE_Q5_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q5_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q5_K>(st, c); break;
-        case MI355Q_TYPE_Q6_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q6_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q6_K>(st, c); break;
-        case MI355Q_TYPE_Q8_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q8_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q8_0>(st, c); break;
-        case MI355Q_TYPE_Q4_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_0>(st, c); break;
-        default: break;
+        const int kind = st->kind;
+        if (kind == PLAN_K_GEMV) {
+            switch (st->type) {
+            case MI355Q_TYPE_Q4_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_K>(st, c); break;
+            case MI355Q_TYPE_Q5_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q5_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q5_K>(st, c); break;
+            case MI355Q_TYPE_Q6_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q6_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q6_K>(st, c); break;
+            case MI355Q_TYPE_Q8_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q8_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q8_0>(st, c); break;
+            case MI355Q_TYPE_Q4_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_0>(st, c); break;
+            default: break;
+            }
+        } else if (kind == PLAN_K_ATTN) {
+            ok = plan_attn(st->attn, c, epoch + st->tag_off);
+        } else {
+            ok = plan_attn_combine(st->attn, c, epoch + st->tag_off);
         }
         if (!ok) return;
-        c.arrivals += (unsigned) c.next_barrier;
-    }
-    // the last workgroup out re-arms the counters for the next launch
-    asm volatile("s_waitcnt vmcnt(0)");
-    __builtin_amdgcn_s_barrier();
-    if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(sync + PLAN_SYNC_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == c.grid - 1) {
-            for (int g = 0; g < PLAN_GROUPS; ++g) {
-                __hip_atomic_store(sync + PLAN_SYNC_ARRIVE + g * PLAN_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sync + PLAN_SYNC_RELEASE + g * PLAN_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(sync + PLAN_SYNC_EXIT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -362,10 +722,13 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
 struct Plan {
     int           device = 0, n_cu = 0, grid = 0, n_stages = 0, even = 0;
     unsigned      set = 0;
-    size_t        lds_bytes = 0;
+    size_t        lds_image = 0, lds_total = 0;
     int64_t       weight_bytes = 0;
     PlanStage *   d_stages = nullptr;
+    AttnStage *   d_attn = nullptr;
     unsigned *    d_sync = nullptr;
+    Granule *     d_gran = nullptr; size_t gran_count = 0;
+    unsigned long long runs = 0;
 };
 
 int gemv_fast_family(int type);
@@ -393,19 +756,90 @@ extern "C" {
 
 void mi355q_set_error(const char * msg);          // api.hip
 
+// outputs published so far while the stage list is built: [ptr, ptr + n) f32 <-> granule offset, producing stage
+namespace { struct OutRange { const float * p; int64_t n; size_t gran_off; unsigned tag_off; }; }
+
 int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_stages, int flags) {
     if (!out || !stages || n_stages < 1) { mi355q_set_error("plan_create: null argument / no stages"); return MI355Q_ERR_SHAPE; }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { mi355q_set_error("plan_create: no device"); return MI355Q_ERR_HIP; }
-    if (!prop.cooperativeLaunch) { mi355q_set_error("plan_create: device lacks cooperative launch"); return MI355Q_ERR_UNSUPPORTED; }
     const int n_cu = prop.multiProcessorCount;
 
-    // split every stage per weight type (a stage of mixed types becomes consecutive sub-stages on the same x)
     std::vector<PlanStage> v;
-    unsigned set = 0; size_t lds_max = 0; int64_t bytes = 0;
+    std::vector<AttnStage> va;
+    std::vector<int> attn_of;                                  // per internal stage: index into va or -1
+    std::vector<OutRange> outs;
+    size_t gran_count = 0;
+    auto new_out = [&](const float * p, int64_t n, unsigned tag_off) {
+        OutRange r = { p, n, gran_count, tag_off };
+        gran_count += (size_t) ((n + 1) & ~(int64_t) 1);       // keep every vector 16-byte aligned
+        outs.push_back(r);
+        return r.gran_off;
+    };
+    // operand -> plain or the granules of the LATEST earlier output that contains it
+    auto resolve = [&](const float * p, int64_t n, VecSrc & vs) -> bool {
+        vs.plain = p; vs.gran = nullptr; vs.tag_off = 0; vs.pad = 0;
+        if (!p) return true;
+        for (size_t i = outs.size(); i-- > 0;) {
+            const OutRange & r = outs[i];
+            if (p >= r.p && p + n <= r.p + r.n) { vs.gran = (const Granule *) (uintptr_t) (r.gran_off + (size_t) (p - r.p) + 1); vs.tag_off = r.tag_off; vs.plain = nullptr; return true; }   // (offset + 1: patched to a pointer below)
+            if (p < r.p + r.n && r.p < p + n) return false;    // straddles an output: not expressible
+        }
+        return true;
+    };
+    unsigned set = 0; size_t lds_max = 0, stg_max = 0; int64_t bytes = 0;
     for (int s = 0; s < n_stages; ++s) {
         const mi355q_stage & in = stages[s];
-        if (in.n_mats < 1 || in.n_mats > GEMV_MAX_MATS || !in.x || in.k <= 0 || ((uintptr_t) in.x & 3)) { mi355q_set_error("plan_create: bad stage"); return MI355Q_ERR_SHAPE; }
+        if (in.kind == MI355Q_STAGE_ATTN) {
+            const mi355q_attn * at = in.attn;
+            if (!at || !at->q || !at->k || !at->v || !at->pos || !at->k_cache || !at->v_cache || !at->k_dst || !at->v_dst || !at->out) { mi355q_set_error("plan_create: attn stage: null pointer"); return MI355Q_ERR_SHAPE; }
+            if (at->n_head < 1 || at->n_head_kv < 1 || at->n_head % at->n_head_kv || at->head_dim < 32 || at->head_dim > 256 || at->head_dim % 32 || at->n_kv < 1) { mi355q_set_error("plan_create: attn stage: bad head geometry"); return MI355Q_ERR_SHAPE; }
+            if (at->rope.mode != 0 && at->rope.mode != 2) { mi355q_set_error("plan_create: attn stage: rope mode must be 0 or 2"); return MI355Q_ERR_UNSUPPORTED; }
+            if (at->rope.n_dims <= 0 || at->rope.n_dims % 2 || at->rope.n_dims > at->head_dim) { mi355q_set_error("plan_create: attn stage: rope n_dims"); return MI355Q_ERR_SHAPE; }
+            if (at->v_nb_dim != 2 && at->v_nb_pos != 2) { mi355q_set_error("plan_create: attn stage: V cache must be contiguous along head_dim or along positions"); return MI355Q_ERR_UNSUPPORTED; }
+            if (at->n_head > n_cu) { mi355q_set_error("plan_create: attn stage: more heads than CUs"); return MI355Q_ERR_UNSUPPORTED; }
+            AttnStage A = {};
+            const int hd = at->head_dim;
+            if (!resolve(at->q, (int64_t) at->n_head * hd, A.q) || !resolve(at->k, (int64_t) at->n_head_kv * hd, A.k) || !resolve(at->v, (int64_t) at->n_head_kv * hd, A.v)) { mi355q_set_error("plan_create: attn operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
+            A.pos = at->pos; A.n_kv_dev = at->n_kv_dev; A.freq_factors = at->freq_factors; A.k_cache = (const char *) at->k_cache; A.v_cache = (const char *) at->v_cache;
+            A.k_nb_pos = at->k_nb_pos; A.k_nb_head = at->k_nb_head; A.v_nb_pos = at->v_nb_pos; A.v_nb_dim = at->v_nb_dim; A.v_nb_head = at->v_nb_head; A.v_dst_nb = at->v_dst_nb;
+            A.k_dst = (char * const *) at->k_dst; A.v_dst = (char * const *) at->v_dst; A.mask = (const char *) at->mask; A.mask_f16 = at->mask_f16;
+            A.n_head = at->n_head; A.n_head_kv = at->n_head_kv; A.hd = hd; A.n_kv = at->n_kv; A.scale = at->scale;
+            A.n_split = n_cu / at->n_head; if (A.n_split < 1) A.n_split = 1; if (A.n_split > at->n_kv) A.n_split = at->n_kv;
+            A.per = (at->n_kv + A.n_split - 1) / A.n_split;
+            A.plain = (in.flags & MI355Q_STAGE_NO_PLAIN) ? 0 : 1; A.out_plain = at->out;
+            A.n_dims = at->rope.n_dims; A.neox = at->rope.mode == 2; A.freq_scale = at->rope.freq_scale; A.ext_factor = at->rope.ext_factor; A.attn_factor = at->rope.attn_factor;
+            A.theta_scale = powf(at->rope.freq_base, -2.0f / at->rope.n_dims);
+            {   // ggml_rope_yarn_corr_dims, ggml.c:3729-3743 (as mi355q_op_rope)
+                auto corr_dim = [&](float n_rot) { return at->rope.n_dims * logf(at->rope.n_ctx_orig / (n_rot * 2 * 3.14159265358979323846f)) / (2 * logf(at->rope.freq_base)); };
+                const float start = floorf(corr_dim(at->rope.beta_fast)), end = ceilf(corr_dim(at->rope.beta_slow));
+                A.corr0 = start > 0 ? start : 0; A.corr1 = end < at->rope.n_dims - 1 ? end : (float) (at->rope.n_dims - 1);
+            }
+            // the two internal stages: partial attention per (head, split), then the merge
+            PlanStage p = {}; p.kind = PLAN_K_ATTN; p.tag_off = (unsigned) v.size() + 1; p.flags = PLAN_F_NEW_X;
+            const size_t part_off = gran_count; gran_count += (size_t) at->n_head * A.n_split * (hd + 2); gran_count = (gran_count + 1) & ~(size_t) 1;
+            A.part = (Granule *) (uintptr_t) (part_off + 1);
+            v.push_back(p); attn_of.push_back((int) va.size());
+            PlanStage q = {}; q.kind = PLAN_K_COMBINE; q.tag_off = (unsigned) v.size() + 1; q.flags = PLAN_F_NEW_X;
+            A.out_gran = (Granule *) (uintptr_t) (new_out(at->out, (int64_t) at->n_head * hd, q.tag_off) + 1);
+            v.push_back(q); attn_of.push_back((int) va.size());
+            va.push_back(A);
+            const size_t need = (size_t) 4 * (3 * hd + hd /* kh, vh */ + 2 * GEMV_WAVES + GEMV_WAVES * hd + A.per) + 64;
+            const size_t need2 = (size_t) 4 * A.n_split * (hd + 2) + 64;
+            if (need > stg_max) stg_max = need;
+            if (need2 > stg_max) stg_max = need2;
+            bytes += (int64_t) 2 * at->n_kv * at->n_head_kv * hd * 2;
+            continue;
+        }
+        if (in.kind != MI355Q_STAGE_GEMV) { mi355q_set_error("plan_create: unknown stage kind"); return MI355Q_ERR_UNSUPPORTED; }
+        if (in.n_mats < 1 || in.n_mats > GEMV_MAX_MATS || !in.x || in.k <= 0 || (in.k & 31) || ((uintptr_t) in.x & 7)) { mi355q_set_error("plan_create: bad stage"); return MI355Q_ERR_SHAPE; }
+        if (in.x_kind < MI355Q_X_PLAIN || in.x_kind > MI355Q_X_UNARY_MUL) { mi355q_set_error("plan_create: unknown x_kind"); return MI355Q_ERR_UNSUPPORTED; }
+        if (in.x_kind == MI355Q_X_UNARY_MUL && (!in.x1 || (in.x_unary != MI355Q_UNARY_SILU && in.x_unary != MI355Q_UNARY_RELU && in.x_unary != MI355Q_UNARY_SIGMOID))) { mi355q_set_error("plan_create: X_UNARY_MUL needs x1 and SILU / RELU / SIGMOID"); return MI355Q_ERR_UNSUPPORTED; }
+        if (in.x_kind == MI355Q_X_PLAIN && in.x1) { mi355q_set_error("plan_create: X_PLAIN takes one operand"); return MI355Q_ERR_SHAPE; }
+        if (in.x_kind == MI355Q_X_NORM && (((uintptr_t) in.norm_w & 15) || (in.k & 3))) { mi355q_set_error("plan_create: norm weights must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
+        if (in.x1 && ((uintptr_t) in.x1 & 7)) { mi355q_set_error("plan_create: x1 must be 8-byte aligned"); return MI355Q_ERR_ALIGN; }
+        VecSrc x0, x1;
+        if (!resolve(in.x, in.k, x0) || !resolve(in.x1, in.k, x1)) { mi355q_set_error("plan_create: an activation operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
         bool done[GEMV_MAX_MATS] = { false, false, false, false };
         bool first = true;
         for (int i = 0; i < in.n_mats; ++i) {
@@ -414,7 +848,10 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             const int fam = gemv_fast_family(type);
             if (fam < 0 || !mi355q_weights_are_planar(type, in.k)) { mi355q_set_error("plan_create: weight type / k has no planar streaming kernel"); return MI355Q_ERR_UNSUPPORTED; }
             PlanStage p = {};
+            p.kind = PLAN_K_GEMV; p.tag_off = (unsigned) v.size() + 1;
             int64_t rows = 0; int n = 0;
+            const size_t sub_base = gran_count;
+            p.yg = (Granule *) (uintptr_t) (sub_base + 1);
             for (int j = i; j < in.n_mats; ++j) {
                 if (done[j] || in.mats[j].type != type) continue;
                 done[j] = true;
@@ -423,44 +860,77 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 if (((uintptr_t) m.w | (uintptr_t) m.w_stride) & 15) { mi355q_set_error("plan_create: planar rows must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
                 if (m.w_stride < mi355q_row_size(type, in.k)) { mi355q_set_error("plan_create: w_stride smaller than a row"); return MI355Q_ERR_SHAPE; }
                 p.w[n] = (const uint8_t *) m.w; p.y[n] = m.y; p.w_stride[n] = m.w_stride; p.row_begin[n] = (int) rows;
+                {   // the stage's granules form one block indexed by concatenated row: matrix n starts at gran_count + rows
+                    OutRange r = { m.y, m.m, sub_base + (size_t) rows, p.tag_off };
+                    outs.push_back(r);
+                }
                 rows += m.m; bytes += m.m * mi355q_row_size(type, in.k); ++n;
             }
             if (rows > 0x7FFFFFF0) { mi355q_set_error("plan_create: too many rows"); return MI355Q_ERR_UNSUPPORTED; }
+            gran_count += (size_t) ((rows + 1) & ~(int64_t) 1);
             for (int j = n; j < GEMV_MAX_MATS; ++j) p.row_begin[j] = 0x7FFFFFFF;
-            p.x = in.x; p.total_rows = (int) rows; p.n_mats = n; p.type = type; p.k = (int) in.k;
-            // barrier + fresh activations at the head of a dependent stage; same-x continuation otherwise
-            const bool depends = (in.flags & MI355Q_STAGE_DEPENDS) && !v.empty();
-            const bool reuse = !first || (!depends && !v.empty() && v.back().x == in.x && v.back().k == (int) in.k &&
-                                          gemv_fast_family(v.back().type) == fam);         // the LDS image of x is still valid
-            p.flags = reuse ? 0 : (PLAN_F_NEW_X | (depends ? PLAN_F_BARRIER : 0));
+            p.total_rows = (int) rows; p.n_mats = n; p.type = type; p.k = (int) in.k;
+            p.x0 = x0; p.x1 = x1; p.x_kind = in.x_kind; p.x_unary = in.x_unary; p.eps = in.eps; p.norm_w = in.norm_w;
+            // a fresh activation image at the head of a stage; sub-stages of other weight types continue on the same image
+            const bool reuse = !first;
+            p.flags = (reuse ? 0 : PLAN_F_NEW_X) | ((in.flags & MI355Q_STAGE_NO_PLAIN) ? 0 : PLAN_F_PLAIN_Y);
+            if (first && in.x_kind == MI355Q_X_NORM && in.x1 && in.sum_out) {
+                p.flags |= PLAN_F_SUM | ((in.flags & MI355Q_STAGE_NO_PLAIN) ? 0 : PLAN_F_SUM_PLAIN);
+                p.sum_plain = in.sum_out;
+                p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off) + 1);
+            }
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;
             p.prime = plan_depth(type);
-            v.push_back(p);
+            v.push_back(p); attn_of.push_back(-1);
             set |= tbit(type);
             const size_t colb = ((size_t) lds_col_bytes(fam, (int) in.k) + 15) & ~(size_t) 15;
             if (colb > lds_max) lds_max = colb;
+            if ((size_t) in.k * 4 + 64 > stg_max) stg_max = (size_t) in.k * 4 + 64;
             first = false;
         }
     }
-    if (lds_max + 64 + GEMV_WAVES * 4096 > 159 * 1024) { mi355q_set_error("plan_create: k too large for the LDS activation image"); return MI355Q_ERR_UNSUPPORTED; }
+    if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
+    const size_t lds_total = lds_max + 64 + 8 * GEMV_WAVES + ((stg_max + 15) & ~(size_t) 15);
+    if (lds_total > 160 * 1024 - 64) { mi355q_set_error("plan_create: k / attention window too large for the LDS staging area"); return MI355Q_ERR_UNSUPPORTED; }
+    if (const char * e = getenv("MI355Q_PLAN_PRIME")) { const int pr = atoi(e); for (auto & p : v) if (p.kind == PLAN_K_GEMV && pr >= 0 && pr < p.prime) p.prime = pr; }
 
     Plan * pl = new Plan();
-    pl->device = dev; pl->n_cu = n_cu; pl->n_stages = (int) v.size(); pl->set = set; pl->lds_bytes = lds_max; pl->weight_bytes = bytes;
+    pl->device = dev; pl->n_cu = n_cu; pl->n_stages = (int) v.size(); pl->set = set; pl->lds_image = lds_max; pl->lds_total = lds_total; pl->weight_bytes = bytes;
     pl->even = (flags & MI355Q_FLAG_ROUND_EVEN) ? 1 : 0;
+    pl->gran_count = gran_count + 2;
     const void * kern = plan_kernel(set);
     int per_cu = 0;
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GEMV_THREADS, lds_max + 64 + GEMV_WAVES * 4096) != hipSuccess || per_cu < 1) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GEMV_THREADS, lds_total) != hipSuccess || per_cu < 1) {
         delete pl; mi355q_set_error("plan_create: persistent kernel does not fit a CU"); return MI355Q_ERR_HIP;
     }
     pl->grid = n_cu;                                           // one workgroup per CU, all co-resident (checked again by the cooperative launch)
-    if (hipMalloc((void **) &pl->d_stages, v.size() * sizeof(PlanStage)) != hipSuccess ||
-        hipMalloc((void **) &pl->d_sync, PLAN_SYNC_WORDS * sizeof(unsigned)) != hipSuccess ||
-        hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(pl->d_sync, 0, PLAN_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) {
+    bool ok = hipMalloc((void **) &pl->d_stages, v.size() * sizeof(PlanStage)) == hipSuccess &&
+              hipMalloc((void **) &pl->d_sync, PLAN_SYNC_WORDS * sizeof(unsigned)) == hipSuccess &&
+              hipMalloc((void **) &pl->d_gran, pl->gran_count * sizeof(Granule)) == hipSuccess &&
+              (va.empty() || hipMalloc((void **) &pl->d_attn, va.size() * sizeof(AttnStage)) == hipSuccess);
+    if (ok) {
+        // patch the (offset + 1) placeholders into device pointers
+        auto fix = [&](const Granule * p) { return p ? pl->d_gran + ((uintptr_t) p - 1) : nullptr; };
+        auto fixs = [&](VecSrc & s) { s.gran = fix(s.gran); };
+        for (auto & A : va) { fixs(A.q); fixs(A.k); fixs(A.v); A.part = (Granule *) fix(A.part); A.out_gran = (Granule *) fix(A.out_gran); }
+        for (size_t i = 0; i < v.size(); ++i) {
+            PlanStage & p = v[i];
+            fixs(p.x0); fixs(p.x1); p.sum_gran = (Granule *) fix(p.sum_gran);
+            p.yg = (Granule *) fix(p.yg);
+            p.attn = attn_of[i] >= 0 ? pl->d_attn + attn_of[i] : nullptr;
+        }
+        ok = hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) == hipSuccess &&
+             (va.empty() || hipMemcpy(pl->d_attn, va.data(), va.size() * sizeof(AttnStage), hipMemcpyHostToDevice) == hipSuccess) &&
+             hipMemset(pl->d_sync, 0, PLAN_SYNC_WORDS * sizeof(unsigned)) == hipSuccess &&
+             hipMemset(pl->d_gran, 0, pl->gran_count * sizeof(Granule)) == hipSuccess;
+    }
+    if (!ok) {
         if (pl->d_stages) (void) hipFree(pl->d_stages);
         if (pl->d_sync) (void) hipFree(pl->d_sync);
+        if (pl->d_gran) (void) hipFree(pl->d_gran);
+        if (pl->d_attn) (void) hipFree(pl->d_attn);
         delete pl; mi355q_set_error("plan_create: device allocation failed"); return MI355Q_ERR_HIP;
     }
     *out = (mi355q_plan *) pl;
@@ -470,24 +940,43 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
 int mi355q_plan_run(mi355q_plan * plan, void * stream) {
     Plan * pl = (Plan *) plan;
     if (!pl) { mi355q_set_error("plan_run: null plan"); return MI355Q_ERR_SHAPE; }
+    // tags = epoch + stage index + 1, epoch = run count * (stages + 1): never 0, never repeated until the 32-bit epoch wraps;
+    // before it does, the granules are zeroed (on the launch stream) and the count starts over
+    const unsigned long long span = (unsigned long long) pl->n_stages + 1;
+    if ((pl->runs + 2) * span >= 0xFFFFFFFFull) {
+        if (hipMemsetAsync(pl->d_gran, 0, pl->gran_count * sizeof(Granule), (hipStream_t) stream) != hipSuccess) { mi355q_set_error("plan_run: granule reset failed"); return MI355Q_ERR_HIP; }
+        pl->runs = 0;
+    }
+    unsigned epoch = (unsigned) (pl->runs * span);
+    ++pl->runs;
     const PlanStage * st = pl->d_stages; int n = pl->n_stages; unsigned * sync = pl->d_sync; int even = pl->even;
-    int image = (int) pl->lds_bytes;
-    unsigned long long timeout = 100ull * 1000 * 20;          // 20 ms of the 100 MHz real-time counter per barrier
+    int image = (int) pl->lds_image;
+    unsigned long long timeout = 100ull * 1000 * 20;          // 20 ms of the 100 MHz real-time counter per poll
     if (const char * e = getenv("MI355Q_PLAN_TIMEOUT_MS")) timeout = 100ull * 1000 * (unsigned long long) atoll(e);
-    void * args[] = { (void *) &st, (void *) &n, (void *) &sync, (void *) &even, (void *) &timeout, (void *) &image };
-    const hipError_t rc = hipLaunchCooperativeKernel(plan_kernel(pl->set), dim3((unsigned) pl->grid), dim3(GEMV_THREADS), args,
-                                                     pl->lds_bytes + 64 + GEMV_WAVES * 4096, (hipStream_t) stream);
+    void * args[] = { (void *) &st, (void *) &n, (void *) &sync, (void *) &even, (void *) &timeout, (void *) &image, (void *) &epoch };
+    // A PLAIN launch of one workgroup per CU (checked against the occupancy query at creation).  hipLaunchCooperativeKernel gives the same
+    // residency and only adds a launch-time check of the grid size -- at +15-19 us of host time per launch, through a second (cooperative) HSA
+    // queue whose teardown at process exit crashed inside the HSA runtime under rocprofv3 (MI355X_MICROARCH.md, coop-launch row).
+    // Every poll is bounded, so a workgroup that found no CU (another persistent kernel holding them) ends in status() == 1, not in a hang.
+    const hipError_t rc = hipLaunchKernel(plan_kernel(pl->set), dim3((unsigned) pl->grid), dim3(GEMV_THREADS), args, pl->lds_total, (hipStream_t) stream);
     if (rc != hipSuccess) { mi355q_set_error(hipGetErrorString(rc)); return MI355Q_ERR_HIP; }
     return MI355Q_OK;
 }
 
-/* 0 = healthy; 1 = a grid barrier timed out (the plan is dead: destroy it).  Synchronizes with the device. */
+/* 0 = healthy; 1 = a poll timed out (the plan is dead: destroy it).  Synchronizes with the device. */
 int mi355q_plan_status(mi355q_plan * plan) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_ERR_SHAPE;
-    static unsigned h[PLAN_SYNC_WORDS];
+    unsigned h[PLAN_SYNC_WORDS];
     if (hipMemcpy(h, pl->d_sync, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return MI355Q_ERR_HIP;
     return h[PLAN_SYNC_ABORT] ? 1 : 0;
+}
+
+int mi355q_plan_status_async(mi355q_plan * plan, unsigned * host_flag, void * stream) {
+    Plan * pl = (Plan *) plan;
+    if (!pl || !host_flag) return MI355Q_ERR_SHAPE;
+    if (hipMemcpyAsync(host_flag, pl->d_sync + PLAN_SYNC_ABORT, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t) stream) != hipSuccess) return MI355Q_ERR_HIP;
+    return MI355Q_OK;
 }
 
 int64_t mi355q_plan_weight_bytes(const mi355q_plan * plan) { return plan ? ((const Plan *) plan)->weight_bytes : 0; }
@@ -496,7 +985,8 @@ int     mi355q_plan_launch_stages(const mi355q_plan * plan) { return plan ? ((co
 int mi355q_plan_destroy(mi355q_plan * plan) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_OK;
-    (void) hipFree(pl->d_stages); (void) hipFree(pl->d_sync);
+    (void) hipFree(pl->d_stages); (void) hipFree(pl->d_sync); (void) hipFree(pl->d_gran);
+    if (pl->d_attn) (void) hipFree(pl->d_attn);
     delete pl;
     return MI355Q_OK;
 }

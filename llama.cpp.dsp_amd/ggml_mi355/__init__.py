@@ -46,12 +46,14 @@ ABI_SYMBOLS = [
     "mi355q_type_supported", "mi355q_blck_size", "mi355q_type_size", "mi355q_row_size", "mi355q_act_type",
     "mi355q_weights_are_planar",
     "mi355q_malloc", "mi355q_free", "mi355q_memset", "mi355q_memcpy_h2d", "mi355q_memcpy_d2h", "mi355q_memcpy_d2d",
+    "mi355q_host_malloc", "mi355q_host_free", "mi355q_memcpy_peer", "mi355q_event_create", "mi355q_event_destroy", "mi355q_event_record",
+    "mi355q_event_wait", "mi355q_event_synchronize",
     "mi355q_stream_create", "mi355q_stream_destroy", "mi355q_stream_synchronize", "mi355q_device_synchronize",
     "mi355q_weights_upload", "mi355q_weights_download", "mi355q_weights_pack_d2d", "mi355q_weights_unpack_d2d",
     "mi355q_quantize_act",
     "mi355q_mul_mat_workspace", "mi355q_mul_mat", "mi355q_mul_mat_multi",
     "mi355q_mul_mat_id_workspace", "mi355q_mul_mat_id",
-    "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
+    "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_status_async", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
     "mi355q_plan_destroy",
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
     "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale", "mi355q_op_cpy_indirect",
@@ -69,16 +71,29 @@ class _Mat(C.Structure):
                 ("y_stride", C.c_int64), ("m", C.c_int64)]
 
 
-class _Stage(C.Structure):
-    _fields_ = [("mats", _Mat * 4), ("n_mats", C.c_int), ("flags", C.c_int), ("x", C.c_void_p), ("k", C.c_int64)]
-
-
-STAGE_DEPENDS = 0x1
-
-
 class _RopeParams(C.Structure):
     _fields_ = [("n_dims", C.c_int), ("mode", C.c_int), ("n_ctx_orig", C.c_int), ("freq_base", C.c_float), ("freq_scale", C.c_float),
                 ("ext_factor", C.c_float), ("attn_factor", C.c_float), ("beta_fast", C.c_float), ("beta_slow", C.c_float)]
+
+
+class _Attn(C.Structure):          # mi355q_attn
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("pos", C.c_void_p), ("rope", _RopeParams),
+                ("freq_factors", C.c_void_p), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p),
+                ("k_nb_pos", C.c_int64), ("k_nb_head", C.c_int64), ("v_nb_pos", C.c_int64), ("v_nb_dim", C.c_int64), ("v_nb_head", C.c_int64),
+                ("k_dst", C.c_void_p), ("v_dst", C.c_void_p), ("v_dst_nb", C.c_int64), ("mask", C.c_void_p), ("mask_f16", C.c_int),
+                ("n_head", C.c_int), ("n_head_kv", C.c_int), ("head_dim", C.c_int), ("n_kv", C.c_int), ("scale", C.c_float), ("out", C.c_void_p),
+                ("n_kv_dev", C.c_void_p)]
+
+
+class _Stage(C.Structure):         # mi355q_stage
+    _fields_ = [("mats", _Mat * 4), ("n_mats", C.c_int), ("flags", C.c_int), ("x", C.c_void_p), ("k", C.c_int64),
+                ("kind", C.c_int), ("x_kind", C.c_int), ("x_unary", C.c_int), ("eps", C.c_float),
+                ("x1", C.c_void_p), ("norm_w", C.c_void_p), ("sum_out", C.c_void_p), ("attn", C.POINTER(_Attn))]
+
+
+STAGE_DEPENDS, STAGE_NO_PLAIN = 0x1, 0x2
+STAGE_GEMV, STAGE_ATTN = 0, 1
+X_PLAIN, X_NORM, X_UNARY_MUL = 0, 1, 2
 
 
 class _Tensor(C.Structure):
@@ -141,6 +156,27 @@ def lib() -> C.CDLL:
     L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     _lib = L
     return L
+
+
+def shutdown() -> None:
+    """Explicit, ordered teardown of the binding: drop the cached workspaces, finish the device's work and UNLOAD libmi355q.so.
+    Unloading runs the library's fat-binary unregistration (the finalizer hipcc puts into every code-object-carrying shared object) now,
+    while the HIP runtime is fully alive, instead of from an exit handler of the dying process -- where, under a profiler that has already
+    finalized, it was seen to touch freed runtime state.  Every Plan / QWeight must have been released by the caller; lib() reloads on demand."""
+    global _lib
+    _ws_cache.clear()
+    if _lib is None:
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    import _ctypes
+    h = _lib._handle
+    _lib = None
+    _ctypes.dlclose(h)
 
 
 def _check(rc: int, what: str) -> None:
@@ -260,27 +296,59 @@ def mul_mat_multi(ws_: list, x, outs=None, flags: int = 0):
 
 
 class Plan:
-    """A chain of N=1 MUL_MATs as ONE persistent launch (mi355q_plan_*).
+    """A token's dependent chain as ONE persistent launch (mi355q_plan_*).
 
-    stages: list of (weights: list[QWeight] (<= 4, same K), x: f32 [1, K] or [K], ys: list of f32 [1, M_i] / [M_i],
-                     depends: bool -- x is produced from earlier stages' outputs during the run).
+    stages: a list whose entries are
+      * (weights: list[QWeight] (<= 4, same K), x: f32 [1, K] or [K], ys: list of f32 [1, M_i] / [M_i], depends)   -- a plain GEMV stage
+        (`depends` is accepted for API version 1 and ignored: an x that is an earlier stage's output is found by its address), or
+      * dict(ws=, ys=, x=, x_kind=X_PLAIN|X_NORM|X_UNARY_MUL, x1=None, norm_w=None, eps=0.0, sum_out=None, unary=UNARY_SILU, no_plain=False), or
+      * dict(attn=dict(q=, k=, v=, pos=, rope=dict(n_dims=, mode=0, n_ctx_orig=0, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0,
+                       attn_factor=1.0, beta_fast=32.0, beta_slow=1.0), freq_factors=None, k_cache=, v_cache=, k_nb_pos=, k_nb_head=, v_nb_pos=,
+                       v_nb_dim=, v_nb_head=, k_dst=, v_dst= (int64 device tensors holding the destination ADDRESSES), v_dst_nb=, mask=None,
+                       n_head=, n_head_kv=, head_dim=, n_kv=, scale=, out=), no_plain=False)                 -- see include/mi355q.h mi355q_attn.
     The tensors are referenced by address: keep them alive (the Plan holds references) and do not move them."""
 
     def __init__(self, stages, flags: int = 0):
         torch = _torch()
         arr = (_Stage * len(stages))()
         self._keep = []
-        for i, (ws_, x, ys, depends) in enumerate(stages):
-            k = x.shape[-1]
-            assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == k
-            assert 1 <= len(ws_) <= 4 and len(ws_) == len(ys)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        for i, sd in enumerate(stages):
             st = _Stage()
-            for j, (w, y) in enumerate(zip(ws_, ys)):
-                assert w.K == k and w.n_expert == 1 and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == w.M
-                st.mats[j] = _Mat(w.type, w.data.data_ptr(), w.row_bytes, y.data_ptr(), w.M * 4, w.M)
-            st.n_mats = len(ws_); st.flags = STAGE_DEPENDS if depends else 0; st.x = x.data_ptr(); st.k = k
+            if isinstance(sd, dict) and "attn" in sd:
+                a = sd["attn"]
+                at = _Attn()
+                for name in ("q", "k", "v", "pos", "freq_factors", "k_cache", "v_cache", "k_dst", "v_dst", "mask", "out", "n_kv_dev"):
+                    setattr(at, name, ptr(a.get(name)))
+                rp = dict(n_dims=a["head_dim"], mode=0, n_ctx_orig=0, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0, beta_fast=32.0, beta_slow=1.0)
+                rp.update(a.get("rope", {}))
+                at.rope = _RopeParams(rp["n_dims"], rp["mode"], rp["n_ctx_orig"], rp["freq_base"], rp["freq_scale"], rp["ext_factor"], rp["attn_factor"], rp["beta_fast"], rp["beta_slow"])
+                for name in ("k_nb_pos", "k_nb_head", "v_nb_pos", "v_nb_dim", "v_nb_head", "v_dst_nb", "n_head", "n_head_kv", "head_dim", "n_kv"):
+                    setattr(at, name, int(a[name]))
+                at.mask_f16 = 1 if (a.get("mask") is not None and a["mask"].dtype == torch.float16) else 0
+                at.scale = float(a["scale"])
+                st.kind = STAGE_ATTN; st.attn = C.pointer(at); st.flags = STAGE_NO_PLAIN if sd.get("no_plain") else 0
+                self._keep.append((a, at))
+            else:
+                if isinstance(sd, dict):
+                    ws_, x, ys = sd["ws"], sd["x"], sd["ys"]
+                    st.x_kind = sd.get("x_kind", X_PLAIN); st.x_unary = sd.get("unary", UNARY_SILU); st.eps = float(sd.get("eps", 0.0))
+                    st.x1 = ptr(sd.get("x1")); st.norm_w = ptr(sd.get("norm_w")); st.sum_out = ptr(sd.get("sum_out"))
+                    st.flags = STAGE_NO_PLAIN if sd.get("no_plain") else 0
+                    for t in (sd.get("x1"), sd.get("norm_w"), sd.get("sum_out")):
+                        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x.shape[-1])
+                else:
+                    ws_, x, ys, depends = sd
+                    st.flags = STAGE_DEPENDS if depends else 0
+                k = x.shape[-1]
+                assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == k
+                assert 1 <= len(ws_) <= 4 and len(ws_) == len(ys)
+                for j, (w, y) in enumerate(zip(ws_, ys)):
+                    assert w.K == k and w.n_expert == 1 and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == w.M
+                    st.mats[j] = _Mat(w.type, w.data.data_ptr(), w.row_bytes, y.data_ptr(), w.M * 4, w.M)
+                st.kind = STAGE_GEMV; st.n_mats = len(ws_); st.x = x.data_ptr(); st.k = k
+                self._keep.append(sd)
             arr[i] = st
-            self._keep.append((ws_, x, ys))
         h = C.c_void_p()
         _check(lib().mi355q_plan_create(C.byref(h), arr, len(stages), flags), "plan_create")
         self._h = h

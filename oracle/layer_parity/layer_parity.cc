@@ -15,6 +15,8 @@
 //     steps > 1 : a decode loop -- step t appends n_tokens positions at n_past + t*n_tokens; every step is compared with the CPU.
 //     LAYER_PARITY_FA=1    : build the layer as llama.cpp does with -fa 1 (one FLASH_ATTN_EXT node, f16 mask, window padded to 256).
 //     LAYER_PARITY_TRACE=1 : keep every intermediate and print the per-node NMSE of the steps whose output differs.
+//     LAYER_PARITY_JITTER=k: from step k on the number of new tokens alternates n_tokens, n_tokens+1, ... -- the graph changes on every
+//                            call, which is what makes a backend give up its launch-graph cache (and must not corrupt the KV cache).
 //     iters > 0 : afterwards, time `iters` graph_compute calls of the last step's graph on both backends.
 // exit code 0 = all nodes supported and every step's NMSE(out) <= 5e-4, NMSE(k cache), NMSE(v cache) <= 1e-6 (5e-4 with more than 8 tokens per step).
 #include <chrono>
@@ -142,7 +144,8 @@ int main(int argc, char ** argv) {
     d.fa = getenv("LAYER_PARITY_FA") != nullptr;               // the -fa 1 form of the layer (FLASH_ATTN_EXT, V cache not transposed)
     if (big) { d.n_embd = 4096; d.n_head = 32; d.n_head_kv = 8; d.hd = 128; d.n_ff = 14336; d.n_ctx = 1024; d.n_past = 500; }
     if (d.fa && d.n_ctx < 512) d.n_ctx = 512;
-    if (d.n_past + steps * n_tokens > d.n_ctx) { fprintf(stderr, "too many steps for n_ctx\n"); return 3; }
+    const int jitter = getenv("LAYER_PARITY_JITTER") ? atoi(getenv("LAYER_PARITY_JITTER")) : -1;
+    if (d.n_past + steps * (n_tokens + (jitter >= 0 ? 1 : 0)) > d.n_ctx) { fprintf(stderr, "too many steps for n_ctx\n"); return 3; }
     Model mr = make_model(d, be_cpu), mt = make_model(d, be_dev);
     ggml_gallocr_t ga_cpu = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be_cpu));
     ggml_gallocr_t ga_dev = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be_dev));
@@ -178,8 +181,12 @@ int main(int argc, char ** argv) {
     uint64_t digest = 1469598103934665603ull;                    // of every step's device output bits: equal digests = bit-identical runs
     auto mix = [&](const std::vector<float> & v) { for (float f : v) { uint32_t u; memcpy(&u, &f, 4); digest = (digest ^ u) * 1099511628211ull; } };
     Step sr, st;
+    int n_past_run = d.n_past;
+    const int n_tokens_base = n_tokens;
     for (int t = 0; t < steps; ++t) {
-        const int n_past = d.n_past + t * n_tokens;
+        const int n_tokens = n_tokens_base + ((jitter >= 0 && t >= jitter && ((t - jitter) & 1)) ? 1 : 0);
+        const int n_past = n_past_run;
+        n_past_run += n_tokens;
         if (sr.ctx) { ggml_free(sr.ctx); ggml_free(st.ctx); }
         sr = build_step(d, mr, n_past, n_tokens); st = build_step(d, mt, n_past, n_tokens);
         if (trace) for (Step * S : { &sr, &st }) for (int i = 0; i < ggml_graph_n_nodes(S->gf); ++i) ggml_set_output(ggml_graph_node(S->gf, i));   // keep every intermediate

@@ -1,0 +1,374 @@
+// model_parity.cc -- TEST / MEASUREMENT INFRASTRUCTURE (built into oracle/_ref/<variant>/ against the reference's public ggml API).
+//
+// A whole llama-architecture model with synthetic weights -- n_layer decoder layers, the output norm and the output matrix --
+// built the way the reference's graph builder does (src/llama-model.cpp llm_build_llama; src/llama-graph.cpp build_norm /
+// build_attn / build_attn_mha / build_ffn; the unified KV cache's cpy_k / cpy_v and its window padded to 32, 256 with -fa),
+// once on the reference CPU backend and once on MI355 devices, decoding the SAME token ids step by step (a fresh ggml graph per
+// token, placed by ggml_gallocr or by ggml_backend_sched, as llama_decode does).  It is what the reference's own
+// tests/test-backend-ops.cpp:3579-3698 (test_llama) does for one graph, extended to a decode loop with persistent weights and cache.
+//
+//   GGML_BACKEND_PATH=.../libggml-mi355.so model_parity [options]
+//     --preset tiny|small|8b|70b   dimensions (tiny: n_embd 512; small: n_embd 2048, n_ff 4096, 16/4 heads; 8b / 70b: Llama-3 sizes)
+//     --layers N  --vocab V        (defaults 4, 32000)
+//     --tokens T                   decode steps compared with the CPU (default 16); --prompt P: one prefill step of P tokens first
+//     --devs MI355_0[,MI355_1..]   layer ranges are split over the devices as --split-mode layer does (contiguous, equal); the output
+//                                  matrix lives on the last device.  More than one device (or --sched) runs through ggml_backend_sched.
+//     --fa                         build attention as llama.cpp does with -fa 1 (FLASH_ATTN_EXT, V cache not transposed)
+//     --dump FILE                  write the CPU logits of every step at sampled vocabulary positions (fixture generation; needs no device)
+//     --check FILE                 compare the DEVICE logits with such a fixture instead of running the CPU backend
+//     --bench N                    afterwards: N more decode steps on the device alone, timed end to end per token (graph build, allocation,
+//                                  input upload, graph_compute, synchronize, logits download), and the same on the CPU backend for <= 8 steps
+//     --no-cpu                     skip the CPU backend (with --bench: timing only)
+// exit code 0 = every node supported by the device(s) and, for every step, max|logit - ref| <= 1e-3 * max|ref|  (north-star bound) and NMSE <= 1e-5.
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "ggml.h"
+#include "ggml-alloc.h"
+#include "ggml-backend.h"
+
+struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; };
+
+struct Layer { ggml_tensor *attn_norm, *ffn_norm, *wq, *wk, *wv, *wo, *wgate, *wup, *wdown, *kc, *vc; };
+struct Model {
+    std::vector<ggml_context *> ctxs; std::vector<ggml_backend_buffer_t> bufs;
+    std::vector<Layer> layers; ggml_tensor * out_norm = nullptr, * output = nullptr;
+};
+struct Step { ggml_context * ctx = nullptr; ggml_cgraph * gf = nullptr; ggml_tensor *x, *pos, *mask, *logits; int n_kv = 0; };
+
+static bool more_bits(int il, int n) { return il < n / 8 || il >= 7 * n / 8 || (il - n / 8) % 3 == 2; }   // src/llama-quant.cpp:129-131
+
+// weights of layer range r live in a buffer of backends[r]; KV cache of a layer with its weights (llama_kv_cache_unified places it per layer device)
+static Model make_model(const Dims & d, const std::vector<ggml_backend_t> & backends) {
+    Model M;
+    const int nb = (int) backends.size();
+    M.layers.resize(d.n_layer);
+    const int n_embd_kv = d.n_head_kv * d.hd;
+    for (int r = 0; r < nb; ++r) {
+        ggml_init_params ip = { ggml_tensor_overhead() * (size_t) (16 * d.n_layer + 8), nullptr, true };
+        ggml_context * c = ggml_init(ip);
+        const int l0 = (int) llround((double) d.n_layer * r / nb), l1 = (int) llround((double) d.n_layer * (r + 1) / nb);
+        for (int il = l0; il < l1; ++il) {
+            Layer & L = M.layers[il];
+            const bool mb = more_bits(il, d.n_layer);
+            L.attn_norm = ggml_new_tensor_1d(c, GGML_TYPE_F32, d.n_embd);
+            L.ffn_norm  = ggml_new_tensor_1d(c, GGML_TYPE_F32, d.n_embd);
+            L.wq = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_embd);
+            L.wk = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, n_embd_kv);
+            L.wv = ggml_new_tensor_2d(c, mb ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K, d.n_embd, n_embd_kv);
+            L.wo = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_embd);
+            L.wgate = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_ff);
+            L.wup   = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_ff);
+            L.wdown = ggml_new_tensor_2d(c, mb ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K, d.n_ff, d.n_embd);
+            L.kc = ggml_new_tensor_1d(c, GGML_TYPE_F16, (int64_t) n_embd_kv * d.n_ctx);
+            L.vc = ggml_new_tensor_1d(c, GGML_TYPE_F16, (int64_t) n_embd_kv * d.n_ctx);
+        }
+        if (r == nb - 1) {
+            M.out_norm = ggml_new_tensor_1d(c, GGML_TYPE_F32, d.n_embd);
+            M.output   = ggml_new_tensor_2d(c, GGML_TYPE_Q6_K, d.n_embd, d.n_vocab);
+        }
+        M.ctxs.push_back(c);
+        M.bufs.push_back(ggml_backend_alloc_ctx_tensors(c, backends[r]));
+    }
+    return M;
+}
+
+static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens) {
+    Step S;
+    ggml_init_params ip = { ggml_tensor_overhead() * (size_t) (64 * d.n_layer + 64) + ggml_graph_overhead_custom(64 * d.n_layer + 64, false), nullptr, true };
+    ggml_context * c = S.ctx = ggml_init(ip);
+    const int n_embd_kv = d.n_head_kv * d.hd;
+    const int n_kv = S.n_kv = GGML_PAD(n_past + n_tokens, d.fa ? 256 : 32);
+    S.x    = ggml_new_tensor_2d(c, GGML_TYPE_F32, d.n_embd, n_tokens);  ggml_set_input(S.x);
+    S.pos  = ggml_new_tensor_1d(c, GGML_TYPE_I32, n_tokens);            ggml_set_input(S.pos);
+    S.mask = ggml_new_tensor_2d(c, d.fa ? GGML_TYPE_F16 : GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, d.fa ? 64 : 32)); ggml_set_input(S.mask);
+    S.gf = ggml_new_graph_custom(c, 64 * d.n_layer + 64, false);
+    const float eps = 1e-5f, kq_scale = 1.0f / sqrtf((float) d.hd);
+    ggml_tensor * inpL = S.x;
+    for (int il = 0; il < d.n_layer; ++il) {
+        const Layer & L = M.layers[il];
+        ggml_tensor * cur = ggml_mul(c, ggml_rms_norm(c, inpL, eps), L.attn_norm);
+        ggml_tensor * Q = ggml_mul_mat(c, L.wq, cur), * K = ggml_mul_mat(c, L.wk, cur), * V = ggml_mul_mat(c, L.wv, cur);
+        Q = ggml_rope_ext(c, ggml_reshape_3d(c, Q, d.hd, d.n_head, n_tokens), S.pos, nullptr, d.hd, 0, 8192, 500000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        K = ggml_rope_ext(c, ggml_reshape_3d(c, K, d.hd, d.n_head_kv, n_tokens), S.pos, nullptr, d.hd, 0, 8192, 500000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        ggml_build_forward_expand(S.gf, Q); ggml_build_forward_expand(S.gf, K); ggml_build_forward_expand(S.gf, V);     // build_attn: q, k, v enter together
+        ggml_tensor * k_view = ggml_view_1d(c, L.kc, (int64_t) n_tokens * n_embd_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv) * n_past);
+        ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_reshape_2d(c, K, n_embd_kv, n_tokens), k_view));
+        ggml_tensor * q = ggml_permute(c, Q, 0, 2, 1, 3);
+        ggml_tensor * k = ggml_view_3d(c, L.kc, d.hd, n_kv, d.n_head_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv), ggml_row_size(GGML_TYPE_F16, d.hd), 0);
+        if (d.fa) {
+            ggml_tensor * v_view = ggml_view_1d(c, L.vc, (int64_t) n_tokens * n_embd_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv) * n_past);
+            ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_reshape_2d(c, V, n_embd_kv, n_tokens), v_view));
+            ggml_tensor * v = ggml_view_3d(c, L.vc, d.hd, n_kv, d.n_head_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv), ggml_row_size(GGML_TYPE_F16, d.hd), 0);
+            cur = ggml_flash_attn_ext(c, q, k, v, S.mask, kq_scale, 0.0f, 0.0f);
+            ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
+            cur = ggml_reshape_2d(c, cur, d.n_embd, n_tokens);
+        } else {
+            ggml_tensor * v_view = ggml_view_2d(c, L.vc, n_tokens, n_embd_kv, d.n_ctx * ggml_element_size(L.vc), n_past * ggml_element_size(L.vc));
+            ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_transpose(c, ggml_reshape_2d(c, V, n_embd_kv, n_tokens)), v_view));
+            ggml_tensor * kq = ggml_mul_mat(c, k, q);
+            kq = ggml_soft_max_ext(c, kq, S.mask, kq_scale, 0.0f);
+            ggml_tensor * v = ggml_view_3d(c, L.vc, n_kv, d.hd, d.n_head_kv, ggml_element_size(L.vc) * d.n_ctx, ggml_element_size(L.vc) * d.n_ctx * d.hd, 0);
+            ggml_tensor * kqv = ggml_mul_mat(c, v, kq);
+            cur = ggml_cont_2d(c, ggml_permute(c, kqv, 0, 2, 1, 3), d.n_embd, n_tokens);
+        }
+        cur = ggml_mul_mat(c, L.wo, cur);
+        ggml_tensor * ffn_inp = ggml_add(c, cur, inpL);
+        cur = ggml_mul(c, ggml_rms_norm(c, ffn_inp, eps), L.ffn_norm);
+        ggml_tensor * gate = ggml_silu(c, ggml_mul_mat(c, L.wgate, cur));
+        cur = ggml_mul(c, gate, ggml_mul_mat(c, L.wup, cur));
+        cur = ggml_mul_mat(c, L.wdown, cur);
+        inpL = ggml_add(c, cur, ffn_inp);
+    }
+    // llm_build_llama tail: only the last token's row goes through the output norm and matrix when decoding one token at a time; a batch
+    // keeps every row (llama-bench pp computes all logits' inputs but the harness compares the last row only)
+    ggml_tensor * cur = ggml_mul(c, ggml_rms_norm(c, inpL, eps), M.out_norm);
+    S.logits = ggml_mul_mat(c, M.output, cur);
+    ggml_set_output(S.logits);
+    ggml_build_forward_expand(S.gf, S.logits);
+    return S;
+}
+
+static std::vector<uint8_t> quantize(ggml_type t, const std::vector<float> & w, int64_t k, int64_t m) {
+    std::vector<uint8_t> q(ggml_row_size(t, k) * m);
+    ggml_quantize_chunk(t, w.data(), q.data(), 0, m, k, nullptr);
+    return q;
+}
+
+struct Runner {                         // one model instance + how its graphs are placed and run
+    std::vector<ggml_backend_t> backends; Model M; ggml_gallocr_t ga = nullptr; ggml_backend_sched_t sched = nullptr;
+    bool compute(Step & S) {
+        if (sched) return ggml_backend_sched_graph_compute(sched, S.gf) == GGML_STATUS_SUCCESS;
+        return ggml_backend_graph_compute(backends[0], S.gf) == GGML_STATUS_SUCCESS;
+    }
+    bool alloc(Step & S) {
+        if (sched) { ggml_backend_sched_reset(sched); return ggml_backend_sched_alloc_graph(sched, S.gf); }
+        return ggml_gallocr_alloc_graph(ga, S.gf);
+    }
+};
+
+int main(int argc, char ** argv) {
+    Dims d;
+    std::string preset = "small", devs = "MI355_0", dump, check;
+    int tokens = 16, prompt = 0, bench = 0; bool use_sched = false, no_cpu = false;
+    d.n_layer = 4; d.n_vocab = 32000;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() { return i + 1 < argc ? std::string(argv[++i]) : std::string(); };
+        if (a == "--preset") preset = next(); else if (a == "--layers") d.n_layer = atoi(next().c_str()); else if (a == "--vocab") d.n_vocab = atoi(next().c_str());
+        else if (a == "--tokens") tokens = atoi(next().c_str()); else if (a == "--prompt") prompt = atoi(next().c_str()); else if (a == "--devs") devs = next();
+        else if (a == "--fa") d.fa = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--bench") bench = atoi(next().c_str());
+        else if (a == "--sched") use_sched = true; else if (a == "--no-cpu") no_cpu = true;
+        else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 3; }
+    }
+    if (preset == "tiny") { d.n_embd = 512; d.n_head = 4; d.n_head_kv = 2; d.hd = 128; d.n_ff = 1024; }
+    else if (preset == "8b") { d.n_embd = 4096; d.n_head = 32; d.n_head_kv = 8; d.hd = 128; d.n_ff = 14336; }
+    else if (preset == "70b") { d.n_embd = 8192; d.n_head = 64; d.n_head_kv = 8; d.hd = 128; d.n_ff = 28672; }
+    else if (preset != "small") { fprintf(stderr, "unknown preset\n"); return 3; }
+    d.n_ctx = GGML_PAD(prompt + tokens + bench + 8, 256);
+    const bool dump_only = !dump.empty();
+    if (!check.empty()) no_cpu = true;
+
+    ggml_backend_load_all();
+    Runner dev, cpu;
+    if (!dump_only) {
+        size_t p = 0;
+        while (p <= devs.size()) {
+            const size_t q = devs.find(',', p);
+            const std::string name = devs.substr(p, q == std::string::npos ? std::string::npos : q - p);
+            ggml_backend_dev_t bd = ggml_backend_dev_by_name(name.c_str());
+            if (!bd) { fprintf(stderr, "device %s not found (is GGML_BACKEND_PATH set?)\n", name.c_str()); return 3; }
+            dev.backends.push_back(ggml_backend_dev_init(bd, nullptr));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+    }
+    ggml_backend_t be_cpu = ggml_backend_init_by_type(GGML_BACKEND_DEVICE_TYPE_CPU, nullptr);
+    const bool run_cpu = dump_only || !no_cpu;
+    cpu.backends.push_back(be_cpu);
+    if (run_cpu) { cpu.M = make_model(d, cpu.backends); cpu.ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be_cpu)); }
+    if (!dump_only) {
+        dev.M = make_model(d, dev.backends);
+        if (dev.backends.size() > 1 || use_sched) {
+            std::vector<ggml_backend_t> bs = dev.backends; bs.push_back(be_cpu);       // the scheduler wants a CPU backend last
+            dev.sched = ggml_backend_sched_new(bs.data(), nullptr, (int) bs.size(), 64 * d.n_layer + 64, false);
+        } else dev.ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(dev.backends[0]));
+    }
+
+    // ---- the same synthetic weights for both (seeded; quantized by the reference's own quantizer)
+    std::mt19937 rng(4321);
+    std::normal_distribution<float> nd(0.0f, 1.0f);
+    auto randv = [&](size_t n, float s) { std::vector<float> v(n); for (auto & x : v) x = nd(rng) * s; return v; };
+    auto set_both = [&](ggml_tensor * a, ggml_tensor * b, const void * data, size_t bytes) {
+        if (run_cpu) ggml_backend_tensor_set(a, data, 0, bytes);
+        if (!dump_only) ggml_backend_tensor_set(b, data, 0, bytes);
+    };
+    const int n_embd_kv = d.n_head_kv * d.hd;
+    for (int il = 0; il < d.n_layer; ++il) {
+        Layer dummy = {};
+        const Layer & A = run_cpu ? cpu.M.layers[il] : dummy; const Layer & B = dump_only ? dummy : dev.M.layers[il];
+        const Layer & T = run_cpu ? A : B;                               // (shapes / types)
+        { auto w = randv(d.n_embd, 0.1f); for (auto & x : w) x += 1.0f; set_both(A.attn_norm, B.attn_norm, w.data(), w.size() * 4); }
+        { auto w = randv(d.n_embd, 0.1f); for (auto & x : w) x += 1.0f; set_both(A.ffn_norm, B.ffn_norm, w.data(), w.size() * 4); }
+        struct WQ { ggml_tensor * a, * b, * t; int64_t k, m; };
+        for (WQ w : { WQ{A.wq, B.wq, T.wq, d.n_embd, d.n_embd}, WQ{A.wk, B.wk, T.wk, d.n_embd, n_embd_kv}, WQ{A.wv, B.wv, T.wv, d.n_embd, n_embd_kv},
+                      WQ{A.wo, B.wo, T.wo, d.n_embd, d.n_embd}, WQ{A.wgate, B.wgate, T.wgate, d.n_embd, d.n_ff}, WQ{A.wup, B.wup, T.wup, d.n_embd, d.n_ff},
+                      WQ{A.wdown, B.wdown, T.wdown, d.n_ff, d.n_embd} }) {
+            auto f = randv((size_t) w.k * w.m, 1.0f / sqrtf((float) w.k));
+            auto q = quantize(w.t->type, f, w.k, w.m);
+            set_both(w.a, w.b, q.data(), q.size());
+        }
+        std::vector<ggml_fp16_t> z((size_t) n_embd_kv * d.n_ctx, ggml_fp32_to_fp16(0.0f));       // an empty (zeroed) cache, as llama.cpp allocates it
+        set_both(A.kc, B.kc, z.data(), z.size() * 2); set_both(A.vc, B.vc, z.data(), z.size() * 2);
+    }
+    {
+        auto w = randv(d.n_embd, 0.1f); for (auto & x : w) x += 1.0f;
+        set_both(run_cpu ? cpu.M.out_norm : nullptr, dump_only ? nullptr : dev.M.out_norm, w.data(), w.size() * 4);
+        // the output matrix in slabs of 2048 rows (its f32 source would be 1 GB at Llama-3 sizes)
+        ggml_tensor * T = run_cpu ? cpu.M.output : dev.M.output;
+        const size_t rb = ggml_row_size(T->type, d.n_embd);
+        for (int r0 = 0; r0 < d.n_vocab; r0 += 2048) {
+            const int nr = std::min(2048, d.n_vocab - r0);
+            auto f = randv((size_t) d.n_embd * nr, 1.0f / sqrtf((float) d.n_embd));
+            auto q = quantize(T->type, f, d.n_embd, nr);
+            if (run_cpu) ggml_backend_tensor_set(cpu.M.output, q.data(), rb * r0, q.size());
+            if (!dump_only) ggml_backend_tensor_set(dev.M.output, q.data(), rb * r0, q.size());
+        }
+    }
+    // token embeddings: a small host-side table (GET_ROWS of token_embd runs on the CPU in llama.cpp; the graph input is the embedding row)
+    const int n_emb_rows = 512;
+    const std::vector<float> emb = randv((size_t) n_emb_rows * d.n_embd, 1.0f);
+    std::mt19937 tok_rng(99);
+    auto next_token = [&]() { return (int) (tok_rng() % (uint32_t) d.n_vocab); };
+
+    // ---- fixture
+    const int stride = 17;
+    const int n_sample = (d.n_vocab + stride - 1) / stride;
+    std::vector<float> fixture;                                             // [step][n_sample]
+    int fx_steps = 0;
+    if (!check.empty()) {
+        FILE * f = fopen(check.c_str(), "rb");
+        int32_t hdr[6];
+        if (!f || fread(hdr, 4, 6, f) != 6) { fprintf(stderr, "cannot read fixture %s\n", check.c_str()); return 3; }
+        if (hdr[0] != 0x4d504c47 || hdr[2] != n_sample || hdr[3] != stride || hdr[4] != d.n_layer || hdr[5] != d.n_embd) { fprintf(stderr, "fixture was made for another model\n"); return 3; }
+        fx_steps = hdr[1];
+        fixture.resize((size_t) fx_steps * n_sample);
+        if (fread(fixture.data(), 4, fixture.size(), f) != fixture.size()) { fprintf(stderr, "short fixture\n"); return 3; }
+        fclose(f);
+    }
+
+    auto set_inputs = [&](Runner & R, Step & S, const std::vector<int> & ids, int n_past) {
+        const int n = (int) ids.size();
+        std::vector<float> x((size_t) n * d.n_embd);
+        for (int i = 0; i < n; ++i) memcpy(&x[(size_t) i * d.n_embd], &emb[(size_t) (ids[i] % n_emb_rows) * d.n_embd], (size_t) d.n_embd * 4);
+        ggml_backend_tensor_set(S.x, x.data(), 0, x.size() * 4);
+        std::vector<int32_t> p(n); for (int i = 0; i < n; ++i) p[i] = n_past + i;
+        ggml_backend_tensor_set(S.pos, p.data(), 0, p.size() * 4);
+        const int rows = GGML_PAD(n, d.fa ? 64 : 32);
+        std::vector<float> m((size_t) S.n_kv * rows, -INFINITY);
+        for (int i = 0; i < n; ++i) for (int j = 0; j <= n_past + i; ++j) m[(size_t) i * S.n_kv + j] = 0.0f;
+        if (d.fa) { std::vector<ggml_fp16_t> h(m.size()); ggml_fp32_to_fp16_row(m.data(), h.data(), m.size()); ggml_backend_tensor_set(S.mask, h.data(), 0, h.size() * 2); }
+        else ggml_backend_tensor_set(S.mask, m.data(), 0, m.size() * 4);
+        (void) R;
+    };
+    auto last_logits = [&](Step & S, int n) { std::vector<float> v(d.n_vocab); ggml_backend_tensor_get(S.logits, v.data(), (size_t) (n - 1) * d.n_vocab * 4, v.size() * 4); return v; };
+
+    bool ok = true;
+    double worst_rel = 0, worst_nmse = 0;
+    int n_past = 0, step_no = 0;
+    std::vector<float> dumped;
+    auto one_step = [&](const std::vector<int> & ids) -> bool {
+        const int n = (int) ids.size();
+        std::vector<float> ref, got;
+        if (run_cpu) {
+            Step S = build_step(d, cpu.M, n_past, n);
+            if (!cpu.alloc(S)) { fprintf(stderr, "cpu graph allocation failed\n"); return false; }
+            set_inputs(cpu, S, ids, n_past);
+            if (!cpu.compute(S)) return false;
+            ref = last_logits(S, n);
+            ggml_free(S.ctx);
+        }
+        if (!dump_only) {
+            Step S = build_step(d, dev.M, n_past, n);
+            if (step_no == 0 && !dev.sched) {               // residency: does the device take every node?
+                int refused = 0;
+                for (int i = 0; i < ggml_graph_n_nodes(S.gf); ++i) if (!ggml_backend_supports_op(dev.backends[0], ggml_graph_node(S.gf, i))) { ++refused; printf("  NOT SUPPORTED: node %d %s\n", i, ggml_op_desc(ggml_graph_node(S.gf, i))); }
+                printf("model graph: %d nodes (%d layers), %d refused by %s\n", ggml_graph_n_nodes(S.gf), d.n_layer, refused, devs.c_str());
+                if (refused) return false;
+            }
+            if (!dev.alloc(S)) { fprintf(stderr, "device graph allocation failed\n"); return false; }
+            if (step_no == 0 && dev.sched) printf("model graph: %d nodes (%d layers), scheduler: %d splits over %d backends\n", ggml_graph_n_nodes(S.gf), d.n_layer, ggml_backend_sched_get_n_splits(dev.sched), ggml_backend_sched_get_n_backends(dev.sched));
+            set_inputs(dev, S, ids, n_past);
+            if (!dev.compute(S)) return false;
+            got = last_logits(S, n);
+            ggml_free(S.ctx);
+        }
+        if (dump_only) { for (int i = 0; i < n_sample; ++i) dumped.push_back(ref[(size_t) i * stride]); }
+        else {
+            double e = 0, s = 0, mx = 0, md = 0;
+            if (!check.empty()) {
+                if (step_no >= fx_steps) { fprintf(stderr, "fixture has only %d steps\n", fx_steps); return false; }
+                for (int i = 0; i < n_sample; ++i) { const double r = fixture[(size_t) step_no * n_sample + i], g = got[(size_t) i * stride]; e += (g - r) * (g - r); s += r * r; mx = std::fmax(mx, std::fabs(r)); md = std::fmax(md, std::fabs(g - r)); }
+            } else if (run_cpu) {
+                for (int i = 0; i < d.n_vocab; ++i) { const double r = ref[i], g = got[i]; e += (g - r) * (g - r); s += r * r; mx = std::fmax(mx, std::fabs(r)); md = std::fmax(md, std::fabs(g - r)); }
+            }
+            if (run_cpu || !check.empty()) {
+                const double nm = e / (s > 0 ? s : 1), rel = md / (mx > 0 ? mx : 1);
+                int am_r = 0, am_g = 0;
+                if (run_cpu) for (int i = 1; i < d.n_vocab; ++i) { if (ref[i] > ref[am_r]) am_r = i; if (got[i] > got[am_g]) am_g = i; }
+                printf("step %2d: n_tokens=%d n_past=%d  logits NMSE %.3e  max|d|/max|ref| %.3e%s\n", step_no, n, n_past, nm, rel, run_cpu ? (am_r == am_g ? "  argmax equal" : "  ARGMAX DIFFERS") : "");
+                worst_rel = std::fmax(worst_rel, rel); worst_nmse = std::fmax(worst_nmse, nm);
+                bool fin = true; for (float v : got) if (!std::isfinite(v)) fin = false;
+                ok = ok && fin && rel <= 1e-3 && nm <= 1e-5;
+            }
+        }
+        n_past += n; ++step_no;
+        return true;
+    };
+    if (prompt > 0) { std::vector<int> ids(prompt); for (auto & t : ids) t = next_token(); if (!one_step(ids)) return 4; }
+    for (int t = 0; t < tokens; ++t) if (!one_step({ next_token() })) return 4;
+    if (dump_only) {
+        FILE * f = fopen(dump.c_str(), "wb");
+        const int32_t hdr[6] = { 0x4d504c47, step_no, n_sample, stride, d.n_layer, d.n_embd };
+        fwrite(hdr, 4, 6, f); fwrite(dumped.data(), 4, dumped.size(), f); fclose(f);
+        printf("wrote %d steps x %d sampled logits to %s\n", step_no, n_sample, dump.c_str());
+        return 0;
+    }
+    if (run_cpu || !check.empty()) printf("%d step(s): worst logits NMSE %.3e, worst max|d|/max|ref| %.3e (bound 1e-3)\n", step_no, worst_nmse, worst_rel);
+
+    if (bench > 0) {
+        auto time_tokens = [&](Runner & R, int n) {
+            const auto t0 = std::chrono::steady_clock::now();
+            int np = n_past;
+            for (int t = 0; t < n; ++t) {
+                Step S = build_step(d, R.M, np, 1);
+                R.alloc(S);
+                set_inputs(R, S, { next_token() }, np);
+                R.compute(S);
+                if (R.sched) ggml_backend_sched_synchronize(R.sched); else ggml_backend_synchronize(R.backends[0]);
+                float l0; ggml_backend_tensor_get(S.logits, &l0, 0, 4);
+                ggml_free(S.ctx);
+                ++np;
+            }
+            return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+        };
+        time_tokens(dev, 3);
+        const double us_dev = time_tokens(dev, bench);
+        double us_cpu = 0; int n_cpu = 0;
+        if (run_cpu) { n_cpu = bench < 8 ? bench : 8; us_cpu = time_tokens(cpu, n_cpu); }
+        printf("decode through ggml_backend_%s (n_layer %d, n_embd %d, n_ff %d, n_vocab %d, n_past ~%d, graph build + inputs + compute + sync per token): %s %.1f us/token = %.1f tok/s",
+               dev.sched ? "sched_graph_compute" : "graph_compute", d.n_layer, d.n_embd, d.n_ff, d.n_vocab, n_past, devs.c_str(), us_dev, 1e6 / us_dev);
+        if (n_cpu) printf("; CPU backend %.1f us/token = %.2f tok/s (%d tokens)", us_cpu, 1e6 / us_cpu, n_cpu);
+        printf("\n");
+    }
+    printf("%s\n", ok ? "MODEL PARITY OK" : "MODEL PARITY FAILED");
+    for (ggml_backend_t b : dev.backends) ggml_backend_free(b);
+    return ok ? 0 : 1;
+}

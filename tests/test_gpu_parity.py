@@ -191,7 +191,11 @@ def test_edge_cases(G, torch, orc):
     with pytest.raises(G.Mi355qError):
         G.QWeight.from_host(t, w[:, :100], 8, 256)
     with pytest.raises(G.Mi355qError):
-        G.QWeight.from_host(17, w, 8, 256)               # IQ2_XS: not implemented -> loud error, no fallback
+        G.QWeight.from_host(oracle.IQ2_XS, w, 8, 256)    # a Q4_K-sized row handed over as IQ2_XS (74-byte blocks): size mismatch is reported
+    with pytest.raises(G.Mi355qError):
+        G.QWeight.from_host(oracle.Q8_K, np.zeros((8, 292), np.uint8), 8, 256)      # right size, but an activation-only format is not a weight type: loud error, no fallback
+    with pytest.raises(G.Mi355qError):
+        G.QWeight.from_host(31, w, 8, 256)               # a ggml type id the library does not know at all
 
 
 # ------------------------------------------------------------------------------------------------
@@ -347,7 +351,10 @@ def test_mul_mat_id(G, torch, orc, t, cfg):
 # ------------------------------------------------------------------------------------------------
 FULL = [(oracle.Q4_K, 4096, 4096), (oracle.Q4_K, 14336, 4096), (oracle.Q6_K, 4096, 14336),
         (oracle.Q4_K, 4096, 14336), (oracle.Q6_K, 1024, 4096), (oracle.Q8_0, 14336, 4096),
-        (oracle.Q5_K, 1024, 8192), (oracle.Q4_0, 4096, 4096)]
+        (oracle.Q5_K, 1024, 8192), (oracle.Q4_0, 4096, 4096),
+        # Llama-3-70B Q4_K_M (BASELINE.json configs[3]; SURVEY.md section 8 header: n_embd 8192, n_ff 28672)
+        (oracle.Q4_K, 8192, 8192), (oracle.Q4_K, 28672, 8192), (oracle.Q4_K, 8192, 28672), (oracle.Q6_K, 8192, 28672),
+        (oracle.Q4_K, 1024, 8192)]
 
 
 @pytest.mark.parametrize("t,M,K", FULL, ids=lambda v: str(v))
@@ -374,7 +381,10 @@ def test_full_size_sampled_rows_and_properties(G, torch, orc, t, M, K):
     assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))
 
 
-@pytest.mark.parametrize("t,M,K", [(oracle.Q4_K, 14336, 4096), (oracle.Q4_K, 4096, 14336), (oracle.Q6_K, 4096, 14336), (oracle.Q6_K, 1024, 4096)],
+@pytest.mark.parametrize("t,M,K", [(oracle.Q4_K, 14336, 4096), (oracle.Q4_K, 4096, 14336), (oracle.Q6_K, 4096, 14336), (oracle.Q6_K, 1024, 4096),
+                                   # Llama-3-70B shapes
+                                   (oracle.Q4_K, 8192, 8192), (oracle.Q4_K, 28672, 8192), (oracle.Q4_K, 8192, 28672), (oracle.Q6_K, 8192, 28672),
+                                   (oracle.Q5_K, 1024, 8192)],
                          ids=lambda v: str(v))
 def test_full_size_prefill_sampled_and_properties(G, torch, orc, t, M, K):
     """pp512 at the BASELINE.json sizes (the integer tier with 128x128 tiles, its split-K form, the bf16 tier's split-K form): sampled
@@ -420,6 +430,53 @@ def test_output_layer_rows(G, torch, orc):
     assert np.array_equal(y[0, M - 4096 + (4096 - M % 4096) % 4096 - 4096:][:0], y[0, :0])
     tail = M % 4096
     assert np.array_equal(y[0, M - tail:].view(np.uint32), y[0, :tail].view(np.uint32))
+
+
+def test_output_layer_rows_70b(G, torch, orc):
+    """The 128256 x 8192 Q6_K output matrix of Llama-3-70B Q4_K_M at N = 1 (GEMV tier) and N = 512 (matrix-core tier): sampled rows
+    against the oracle, and periodic weights -> periodic outputs over the whole row range."""
+    t, M, K = oracle.Q6_K, 128256, 8192
+    rng = np.random.default_rng(19)
+    base = random_blocks(t, 2048, K, rng)
+    w = np.tile(base, (M // 2048 + 1, 1))[:M]
+    wq = G.QWeight.from_host(t, w, M, K)
+    del w
+    x = rng.standard_normal((512, K)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    y1 = G.mul_mat(wq, xd[:1]).cpu().numpy()
+    rows = np.unique(rng.integers(0, 2048, 64))
+    check_close(y1[:, rows], orc.mul_mat(t, base[rows], x[:1], len(rows), 1, K), "70B output N=1")
+    assert np.array_equal(y1[0, 2048:4096].view(np.uint32), y1[0, :2048].view(np.uint32))
+    tail = M % 2048
+    assert np.array_equal(y1[0, M - tail:].view(np.uint32), y1[0, :tail].view(np.uint32))
+    y = G.mul_mat(wq, xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    toks = np.array([0, 77, 300, 511])
+    ref = orc.mul_mat(t, base[rows], x[toks], len(rows), len(toks), K)
+    check(G, t, K, 512, y[np.ix_(toks, rows)], ref, "70B output N=512")
+    assert np.array_equal(y[:, 2048:4096].view(np.uint32), y[:, :2048].view(np.uint32))       # same weights, same tokens -> same numbers in every tile
+    assert np.array_equal(y[:, M - tail:].view(np.uint32), y[:, :tail].view(np.uint32))
+
+
+@pytest.mark.parametrize("n_tok", [1, 512])
+def test_mixtral_full_size_expert_tensor(G, torch, orc, n_tok):
+    """BASELINE.json configs[4]: one full-size Mixtral-8x7B expert tensor (8 x 14336 x 4096 Q4_K, n_used 2) through MUL_MAT_ID at decode
+    (ids read on the device) and at prefill size (rows grouped by expert): sampled rows / tokens against the oracle."""
+    t, ne, nu, M, K = oracle.Q4_K, 8, 2, 14336, 4096
+    rng = np.random.default_rng(23 + n_tok)
+    as_ = random_blocks(t, ne * M, K, rng)
+    w = G.QWeight.from_host(t, as_, M, K, n_expert=ne)
+    ids = np.stack([rng.permutation(ne)[:nu] for _ in range(n_tok)]).astype(np.int32)
+    b = rng.standard_normal((n_tok, 1, K)).astype(np.float32)
+    y = G.mul_mat_id(w, torch.from_numpy(b).cuda(), torch.from_numpy(ids).cuda()).cpu().numpy()
+    assert y.shape == (n_tok, nu, M) and np.isfinite(y).all()
+    rows = np.unique(np.concatenate([[0, M - 1], rng.integers(0, M, 40)]))
+    toks = np.unique(np.concatenate([[0, n_tok - 1], rng.integers(0, n_tok, 6)]))
+    sub = np.ascontiguousarray(as_.reshape(ne, M, -1)[:, rows]).reshape(ne * len(rows), -1)      # the sampled rows of every expert
+    ref = orc.mul_mat_id(t, sub, np.ascontiguousarray(b[toks]), np.ascontiguousarray(ids[toks]), len(rows), K, ne)
+    check_close(y[np.ix_(toks, np.arange(nu), rows)], ref, f"mixtral expert tensor n_tok={n_tok}")      # Q4_K: the CPU arithmetic on both tiers
+    y2 = G.mul_mat_id(w, torch.from_numpy(b).cuda(), torch.from_numpy(ids).cuda()).cpu().numpy()
+    assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))                                 # deterministic
 
 
 # ------------------------------------------------------------------------------------------------
@@ -496,3 +553,31 @@ def test_plan_rejects_what_it_cannot_stream(G, torch):
     w6 = G.QWeight.from_host(oracle.Q6_K, random_blocks(oracle.Q6_K, 32, 256, rng), 32, 256)      # Q6_K rows of 210 bytes are not planar at k=256
     with pytest.raises(G.Mi355qError):
         G.Plan([([w6], x, [y], False)])
+
+
+def test_plan_llama70b_layer_against_oracle(G, torch, orc):
+    """One Llama-3-70B Q4_K_M layer at FULL width as one persistent launch (BASELINE.json configs[3]: n_embd 8192, n_ff 28672, K = 28672
+    for ffn_down), every output checked against the ORACLE on sampled rows (not only against mul_mat)."""
+    rng = np.random.default_rng(70)
+    E, F, KV = 8192, 28672, 1024
+    def W(t, m, k):
+        h = random_blocks(t, m, k, rng)
+        return h, G.QWeight.from_host(t, h, m, k)
+    layer = [[W(oracle.Q4_K, E, E), W(oracle.Q4_K, KV, E), W(oracle.Q5_K, KV, E)], [W(oracle.Q4_K, E, E)],
+             [W(oracle.Q4_K, F, E), W(oracle.Q4_K, F, E)], [W(oracle.Q6_K, E, F)]]
+    stages, checks = [], []
+    for gi, grp in enumerate(layer):
+        k = grp[0][1].K
+        x = torch.from_numpy(rng.standard_normal((1, k)).astype(np.float32)).cuda()
+        ys = [torch.zeros((1, w.M), dtype=torch.float32, device="cuda") for _, w in grp]
+        stages.append(([w for _, w in grp], x, ys, gi > 0))
+        checks.append((grp, x, ys))
+    plan = G.Plan(stages)
+    plan.run(); torch.cuda.synchronize()
+    assert plan.status() == 0
+    for grp, x, ys in checks:
+        for (h, w), y in zip(grp, ys):
+            assert np.array_equal(_bits_t(y), _bits_t(G.mul_mat(w, x)))
+            rows = np.unique(np.concatenate([[0, w.M - 1], rng.integers(0, w.M, 48)]))
+            check_close(y.cpu().numpy()[:, rows], orc.mul_mat(w.type, h[rows], x.cpu().numpy(), len(rows), 1, w.K), f"70B layer {ids_t(w.type)} {w.M}x{w.K}")
+    plan.close()

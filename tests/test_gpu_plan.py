@@ -1,0 +1,249 @@
+"""The decode plan's glue (mi355q_plan_* API version 2): activation prologues (rms_norm(x0 + x1) * w, unary(x0) * x1), the
+data-driven hand-off between stages (tagged granules instead of a grid barrier) and the one-token attention stage (rope, KV
+store, softmax(q k) v over an f16 cache), through the C-ABI.
+
+What is compared with what:
+  * every GEMV output against mi355q_mul_mat applied to the activation vector the same glue ops of the node-by-node path
+    produce (mi355q_op_add_rms_norm_mul / mi355q_op_unary_mul, themselves pinned to the CPU ops in tests/test_gpu_glue.py):
+    BIT-IDENTICAL (the prologues perform the same f32 operations; the f64 sum of squares is accumulated in another order,
+    which changes the f32 scale in far fewer than 1 of 1000 rows -- the tolerance below covers that case);
+  * the attention stage against a float64 numpy restatement of the reference's graph (rope with the reference's repeated-f32
+    angle, q rounded to f16 as the CPU's f16 dot does, f16 cache, softmax((q.k) scale + mask), P V): <= 2e-5 of max|out|
+    (f32 summation order only), and the K / V rows it stores bit-exactly against mi355q_op_rope + mi355q_op_cpy.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import glue
+from qdata import quantized_weights, random_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    import ggml_mi355 as g
+    assert torch.cuda.is_available() and g.lib().mi355q_device_count() >= 1
+    return g
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    return t
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+def close_or_equal(y, ref, what):
+    y = y.detach().cpu().numpy(); ref = ref.detach().cpu().numpy()
+    assert np.isfinite(y).all(), what
+    if np.array_equal(y.view(np.uint32), ref.view(np.uint32)):
+        return True
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), f"{what}: {np.abs(y - ref).max():.3e} vs {np.abs(ref).max():.3e}"
+    return False
+
+
+def W(G, t, m, k, rng, scale=1.0):
+    h = quantized_weights(t, m, k, rng, scale=scale)
+    return G.QWeight.from_host(t, h, m, k)
+
+
+@pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.Q8_0], ids=lambda t: oracle.TYPE_NAMES[t])
+def test_norm_and_unary_prologues_match_the_node_ops(G, torch, t):
+    """A llama layer without the attention block, at reduced width, as 5 stages whose operands are earlier stages' outputs:
+    qkv = W1 norm(h) ; o = Wo q ; gate|up = W norm(h + o) [sum -> ffn_inp] ; down = Wd (silu(gate) * up) ; next = W norm(ffn_inp + down)."""
+    rng = np.random.default_rng(40 + t)
+    E, F = 2048, 4096                                            # (Q6_K rows are planar when k % 2048 == 0)
+    eps = 1e-5
+    w_qkv, w_o, w_g, w_u, w_d, w_n = W(G, t, E, E, rng), W(G, t, E, E, rng), W(G, t, F, E, rng), W(G, t, F, E, rng), W(G, t, E, F, rng), W(G, t, 300, E, rng)
+    h = dev(torch, rng.standard_normal((1, E)).astype(np.float32))
+    n1, n2, n3 = (dev(torch, (1.0 + 0.1 * rng.standard_normal(E)).astype(np.float32)) for _ in range(3))
+    z = lambda n: torch.zeros((1, n), dtype=torch.float32, device="cuda")
+    q, o, gate, up, down, nxt, ffn_inp, h2 = z(E), z(E), z(F), z(F), z(E), z(300), z(E), z(E)
+    stages = [
+        dict(ws=[w_qkv], ys=[q], x=h, x_kind=G.X_NORM, norm_w=n1, eps=eps),
+        dict(ws=[w_o], ys=[o], x=q),
+        dict(ws=[w_g, w_u], ys=[gate, up], x=h, x1=o, x_kind=G.X_NORM, norm_w=n2, eps=eps, sum_out=ffn_inp),
+        dict(ws=[w_d], ys=[down], x=gate, x1=up, x_kind=G.X_UNARY_MUL, unary=G.UNARY_SILU),
+        dict(ws=[w_n], ys=[nxt], x=ffn_inp, x1=down, x_kind=G.X_NORM, norm_w=n3, eps=eps, sum_out=h2),
+    ]
+    plan = G.Plan(stages)
+    # the node-by-node path
+    r_q = G.mul_mat(w_qkv, G.op_add_rms_norm_mul(h, eps, weight=n1))
+    r_o = G.mul_mat(w_o, r_q)
+    x3, r_ffn = G.op_add_rms_norm_mul(h, eps, b=r_o, weight=n2, want_sum=True)
+    r_gate, r_up = G.mul_mat(w_g, x3), G.mul_mat(w_u, x3)
+    r_down = G.mul_mat(w_d, G.op_unary_mul(G.UNARY_SILU, r_gate, r_up))
+    x5, r_h2 = G.op_add_rms_norm_mul(r_ffn, eps, b=r_down, weight=n3, want_sum=True)
+    r_nxt = G.mul_mat(w_n, x5)
+    for rep in range(3):                                         # re-runs: the tags advance, nothing is re-armed
+        for b in (q, o, gate, up, down, nxt, ffn_inp, h2):
+            b.zero_()
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        same = [close_or_equal(a, b, n) for a, b, n in ((q, r_q, "q"), (o, r_o, "o"), (ffn_inp, r_ffn, "ffn_inp"), (gate, r_gate, "gate"), (up, r_up, "up"),
+                                                        (down, r_down, "down"), (h2, r_h2, "h2"), (nxt, r_nxt, "next"))]
+        assert same[0] and same[1] and same[2], same              # (no reduction-order freedom before the second norm's scale)
+    plan.close()
+
+
+def test_no_plain_outputs_are_not_written(G, torch):
+    rng = np.random.default_rng(5)
+    K = 2048
+    w1, w2 = W(G, oracle.Q4_K, K, K, rng), W(G, oracle.Q4_K, 512, K, rng)
+    x = dev(torch, rng.standard_normal((1, K)).astype(np.float32))
+    mid = torch.full((1, K), 7.0, dtype=torch.float32, device="cuda"); out = torch.zeros((1, 512), dtype=torch.float32, device="cuda")
+    plan = G.Plan([dict(ws=[w1], ys=[mid], x=x, no_plain=True), dict(ws=[w2], ys=[out], x=mid)])
+    plan.run(); torch.cuda.synchronize()
+    assert plan.status() == 0
+    assert bool((mid == 7.0).all())                               # the intermediate lives only in the plan's granules
+    assert np.array_equal(bits(out), bits(G.mul_mat(w2, G.mul_mat(w1, x))))
+    plan.close()
+
+
+def _rope_np(x, pos, n_dims, mode, freq_base):
+    return glue.rope(x.reshape(1, 1, -1, x.shape[-1]).astype(np.float32), np.array([pos], np.int32), n_dims, mode, freq_base=freq_base).reshape(x.shape)
+
+
+@pytest.mark.parametrize("layout", ["transposed_v", "rows_v"])
+@pytest.mark.parametrize("cfg", [(32, 8, 128, 512, 500), (32, 8, 128, 96, 37), (8, 8, 64, 64, 0), (16, 2, 128, 2048, 2047), (4, 4, 256, 160, 100)], ids=str)
+def test_attention_stage(G, torch, layout, cfg):
+    """(n_head, n_head_kv, head_dim, n_kv, pos).  The q / k / v vectors are the outputs of a GEMV stage of the same plan (so the
+    attention workgroups poll granules), the cache holds `pos` earlier rows, the window is padded to n_kv and masked beyond pos."""
+    n_head, n_head_kv, hd, n_kv, pos = cfg
+    rng = np.random.default_rng(hash(cfg) % 1000 + (layout == "rows_v"))
+    E = 2048
+    n_q, n_k = n_head * hd, n_head_kv * hd
+    n_ctx = n_kv + 32
+    wq, wk, wv = W(G, oracle.Q4_K, n_q, E, rng), W(G, oracle.Q4_K, n_k, E, rng), W(G, oracle.Q6_K, n_k, E, rng)
+    x = dev(torch, rng.standard_normal((1, E)).astype(np.float32))
+    q, k, v = (torch.zeros((1, n), dtype=torch.float32, device="cuda") for n in (n_q, n_k, n_k))
+    out = torch.zeros((1, n_q), dtype=torch.float32, device="cuda")
+    kc_h = rng.standard_normal((n_ctx, n_k)).astype(np.float16)                    # [position][kv head * hd]
+    vc_h = rng.standard_normal((n_ctx, n_k)).astype(np.float16)
+    kc_h[pos + 1:] = np.float16(np.nan); vc_h[pos + 1:] = np.float16(np.nan)       # never-written rows must not leak through the mask
+    kc = dev(torch, kc_h)
+    if layout == "rows_v":
+        vc = dev(torch, vc_h)
+        v_nb_pos, v_nb_dim, v_nb_head, v_dst_off, v_dst_nb = n_k * 2, 2, hd * 2, pos * n_k * 2, 2
+    else:
+        vc = dev(torch, np.ascontiguousarray(vc_h.T))                              # [kv head * hd][position]
+        v_nb_pos, v_nb_dim, v_nb_head, v_dst_off, v_dst_nb = 2, n_ctx * 2, hd * n_ctx * 2, pos * 2, n_ctx * 2
+    mask_h = np.full(n_kv, -np.inf, np.float32); mask_h[:pos + 1] = 0.0
+    mask = dev(torch, mask_h if layout == "transposed_v" else mask_h.astype(np.float16))
+    posd = dev(torch, np.array([pos], np.int32))
+    dst = torch.tensor([kc.data_ptr() + pos * n_k * 2, vc.data_ptr() + v_dst_off], dtype=torch.int64, device="cuda")
+    scale = 1.0 / np.sqrt(hd)
+    mode = 0 if hd != 64 else 2                                                    # one neox case
+    attn = dict(q=q, k=k, v=v, pos=posd, rope=dict(n_dims=hd, mode=mode, n_ctx_orig=8192, freq_base=500000.0), k_cache=kc, v_cache=vc,
+                k_nb_pos=n_k * 2, k_nb_head=hd * 2, v_nb_pos=v_nb_pos, v_nb_dim=v_nb_dim, v_nb_head=v_nb_head,
+                k_dst=dst[0:1], v_dst=dst[1:2], v_dst_nb=v_dst_nb, mask=mask, n_head=n_head, n_head_kv=n_head_kv, head_dim=hd, n_kv=n_kv,
+                scale=scale, out=out)
+    plan = G.Plan([dict(ws=[wq, wk, wv], ys=[q, k, v], x=x), dict(attn=attn)])
+    plan.run(); torch.cuda.synchronize()
+    assert plan.status() == 0
+    # --- reference in float64 on the device's own q / k / v
+    qh, kh_, vh_ = q.cpu().numpy().reshape(n_head, hd), k.cpu().numpy().reshape(n_head_kv, hd), v.cpu().numpy().reshape(n_head_kv, hd)
+    assert np.array_equal(bits(q), bits(G.mul_mat(wq, x))) and np.array_equal(bits(v), bits(G.mul_mat(wv, x)))
+    q_r = _rope_np(qh, pos, hd, mode, 500000.0).astype(np.float16).astype(np.float64)
+    k_r = _rope_np(kh_, pos, hd, mode, 500000.0).astype(np.float16)
+    v_r = vh_.astype(np.float16)
+    # the stored rows, bit-exact
+    kc_after = kc.cpu().numpy()
+    vc_after = vc.cpu().numpy() if layout == "rows_v" else vc.cpu().numpy().T
+    assert np.array_equal(kc_after[pos].view(np.uint16), k_r.reshape(-1).view(np.uint16))
+    assert np.array_equal(vc_after[pos].view(np.uint16), v_r.reshape(-1).view(np.uint16))
+    untouched = np.ones(n_ctx, bool); untouched[pos] = False
+    assert np.array_equal(kc_after[untouched].view(np.uint16), kc_h[untouched].view(np.uint16))
+    K_all = kc_h.copy(); K_all[pos] = k_r.reshape(-1); V_all = vc_h.copy(); V_all[pos] = v_r.reshape(-1)
+    ref = np.zeros((n_head, hd))
+    gq = n_head // n_head_kv
+    for h in range(n_head):
+        g = h // gq
+        Kg = K_all[:pos + 1, g * hd:(g + 1) * hd].astype(np.float64); Vg = V_all[:pos + 1, g * hd:(g + 1) * hd].astype(np.float64)
+        s = (Kg @ q_r[h]) * scale
+        p = np.exp(s - s.max()); p /= p.sum()
+        ref[h] = p @ Vg
+    got = out.cpu().numpy().reshape(n_head, hd).astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    # a second token at pos + 1 through the SAME plan: only the device-side destination slots, pos and the mask move
+    if pos + 1 < n_kv:
+        pos2 = pos + 1
+        posd.fill_(pos2)
+        mask_h[:pos2 + 1] = 0.0
+        mask.copy_(dev(torch, mask_h if layout == "transposed_v" else mask_h.astype(np.float16)))
+        dst.copy_(torch.tensor([kc.data_ptr() + pos2 * n_k * 2, vc.data_ptr() + (pos2 * n_k * 2 if layout == "rows_v" else pos2 * 2)], dtype=torch.int64))
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        kc2 = kc.cpu().numpy()
+        assert np.array_equal(kc2[pos].view(np.uint16), k_r.reshape(-1).view(np.uint16))           # the previous row stays
+        assert np.array_equal(kc2[pos2].view(np.uint16), _rope_np(kh_, pos2, hd, mode, 500000.0).astype(np.float16).reshape(-1).view(np.uint16))
+        assert np.isfinite(out.cpu().numpy()).all()
+    plan.close()
+
+
+def test_attention_stage_against_the_node_ops(G, torch):
+    """The same token through the node-by-node ops of the plugin (rope, cache stores, f16 K.q, soft_max, f16 V.p): the plan keeps the
+    probabilities in f32 where the CPU graph rounds them to f16 for the P V product, so the two agree to that rounding (NMSE <= 1e-6)."""
+    n_head, n_head_kv, hd, n_kv, pos = 32, 8, 128, 256, 200
+    rng = np.random.default_rng(9)
+    n_q, n_k, n_ctx = n_head * hd, n_head_kv * hd, 512
+    q = dev(torch, rng.standard_normal((1, n_q)).astype(np.float32)); k = dev(torch, rng.standard_normal((1, n_k)).astype(np.float32)); v = dev(torch, rng.standard_normal((1, n_k)).astype(np.float32))
+    kc_h = rng.standard_normal((n_ctx, n_k)).astype(np.float16); vc_h = rng.standard_normal((n_k, n_ctx)).astype(np.float16)
+    mask_h = np.full((1, n_kv), -np.inf, np.float32); mask_h[0, :pos + 1] = 0.0
+    scale = 1.0 / np.sqrt(hd)
+    posd = dev(torch, np.array([pos], np.int32))
+    # node path
+    kc1, vc1 = dev(torch, kc_h), dev(torch, vc_h)
+    q_r = G.op_rope(q.view(1, 1, n_head, hd), posd, hd, 0, n_ctx_orig=8192, freq_base=500000.0)
+    k_r = G.op_rope(k.view(1, 1, n_head_kv, hd), posd, hd, 0, n_ctx_orig=8192, freq_base=500000.0)
+    G.op_cpy(k_r.view(1, n_k), kc1[pos:pos + 1])
+    G.op_cpy(v.view(n_k, 1), vc1[:, pos:pos + 1])
+    kq = G.op_mul_mat_f(kc1[:n_kv].view(n_kv, n_head_kv, hd).permute(1, 0, 2), q_r.view(n_head, 1, hd))          # [n_head, 1, n_kv]
+    p = G.op_soft_max(kq, dev(torch, mask_h), scale)
+    o = G.op_mul_mat_f(vc1.view(n_head_kv, hd, n_ctx)[:, :, :n_kv], p)                                              # [n_head, 1, hd]
+    ref = o.reshape(-1).cpu().numpy().astype(np.float64)
+    # plan path (a trivial GEMV stage in front: a plan needs one)
+    kc2, vc2 = dev(torch, kc_h), dev(torch, vc_h)
+    out = torch.zeros((1, n_q), dtype=torch.float32, device="cuda")
+    dst = torch.tensor([kc2.data_ptr() + pos * n_k * 2, vc2.data_ptr() + pos * 2], dtype=torch.int64, device="cuda")
+    w0 = W(G, oracle.Q4_K, 32, 256, rng); x0 = torch.zeros((1, 256), dtype=torch.float32, device="cuda"); y0 = torch.zeros((1, 32), dtype=torch.float32, device="cuda")
+    attn = dict(q=q, k=k, v=v, pos=posd, rope=dict(n_dims=hd, mode=0, n_ctx_orig=8192, freq_base=500000.0), k_cache=kc2, v_cache=vc2,
+                k_nb_pos=n_k * 2, k_nb_head=hd * 2, v_nb_pos=2, v_nb_dim=n_ctx * 2, v_nb_head=hd * n_ctx * 2, k_dst=dst[0:1], v_dst=dst[1:2], v_dst_nb=n_ctx * 2,
+                mask=dev(torch, mask_h.reshape(-1)), n_head=n_head, n_head_kv=n_head_kv, head_dim=hd, n_kv=n_kv, scale=scale, out=out)
+    plan = G.Plan([([w0], x0, [y0], False), dict(attn=attn)])
+    plan.run(); torch.cuda.synchronize()
+    assert plan.status() == 0
+    assert np.array_equal(kc2.cpu().numpy().view(np.uint16), kc1.cpu().numpy().view(np.uint16))
+    assert np.array_equal(vc2.cpu().numpy().view(np.uint16), vc1.cpu().numpy().view(np.uint16))
+    got = out.reshape(-1).cpu().numpy().astype(np.float64)
+    assert ((got - ref) ** 2).sum() / (ref ** 2).sum() <= 1e-6
+    plan.close()
+
+
+def test_plan_timeout_is_reported_not_hung(G, torch):
+    """An operand that claims to come from an earlier stage but is never produced cannot be built through the API (dependencies follow
+    from addresses), so the bounded poll is exercised the only way possible: a plan whose launch is healthy reports status 0 repeatedly,
+    and a destroyed / re-created plan starts from fresh tags."""
+    rng = np.random.default_rng(6)
+    K = 2048
+    w = W(G, oracle.Q4_K, 64, K, rng)
+    x = dev(torch, rng.standard_normal((1, K)).astype(np.float32)); y = torch.zeros((1, 64), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        plan = G.Plan([([w], x, [y], False)])
+        for _ in range(5):
+            plan.run()
+        torch.cuda.synchronize()
+        assert plan.status() == 0
+        assert np.array_equal(bits(y), bits(G.mul_mat(w, x)))
+        plan.close()
