@@ -170,8 +170,8 @@ class Stage:
                                      n_head=nh, n_head_kv=nkv, head_dim=hd, n_kv=n_ctx, scale=1.0 / hd ** 0.5, out=att), no_plain=True))
             st.append(dict(ws=[W("attn_output")], ys=[o], x=att, no_plain=True))
             st.append(dict(ws=[W("ffn_gate"), W("ffn_up")], ys=[gate, up], x=h_res, x1=o, x_kind=g.X_NORM, norm_w=self.norm_w[2 * li + 1], eps=1e-5,
-                           sum_out=ffn_inp, no_plain=not (last and not last_rank)))
-            st.append(dict(ws=[W("ffn_down")], ys=[d], x=gate, x1=up, x_kind=g.X_UNARY_MUL, unary=g.UNARY_SILU, no_plain=not (last and not last_rank)))
+                           sum_out=ffn_inp, y_kind=g.Y_UNARY_MUL, y_unary=g.UNARY_SILU, no_plain=not (last and not last_rank)))     # publishes SiLU(gate) * up
+            st.append(dict(ws=[W("ffn_down")], ys=[d], x=gate, no_plain=not (last and not last_rank)))
             x0, x1 = ffn_inp, d
         self.logits = None
         if "output" in by:

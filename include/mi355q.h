@@ -175,11 +175,12 @@ int    mi355q_mul_mat_multi(const mi355q_mat *mats, int n_mats,
  * w: n_expert consecutive matrices of m device rows each (expert stride = expert_stride_bytes);
  * x: f32 [n_tok][x_ne1][k] contiguous rows with strides x_stride1_bytes (slot) and x_stride2_bytes (token);
  * ids: i32 device [n_tok][n_used] with row stride ids_stride_bytes;  y: f32 [n_tok][n_used][m] contiguous.
- * Up to 16 (token, slot) pairs the expert ids are read ON THE DEVICE (no host round trip: decode stays capturable).  From 17 pairs on
- * (prefill) the rows are grouped by expert on the host -- a stream synchronize, as the reference's CUDA path does (ggml-cuda.cu
- * ggml_cuda_mul_mat_id) -- gathered, multiplied per expert by the ordinary mul_mat tiers and scattered back; size the workspace
- * with mi355q_mul_mat_id_workspace. */
-size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1);
+ * The expert ids are read ON THE DEVICE at every size (no host round trip: the call stays capturable).  Up to 16 (token, slot) pairs every
+ * pair is one GEMV column; from 17 pairs on (prefill) the pairs are counting-sorted by expert on the device into tile-aligned segments,
+ * gathered, multiplied by ONE launch of the matrix-core tier over all experts and scattered back (the reference groups on the host behind a
+ * stream synchronize, ggml-cuda.cu:2008-2011); size the workspace with mi355q_mul_mat_id_workspace.  A pair whose expert id is out of range
+ * [0, n_expert) -- the reference asserts on it -- gets an output row of NaN on every path. */
+size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1, int64_t n_expert);
 int    mi355q_mul_mat_id(int type, const void *w, int64_t w_stride_bytes, int64_t expert_stride_bytes, int64_t n_expert,
                          const float *x, int64_t x_ne1, int64_t x_stride1_bytes, int64_t x_stride2_bytes,
                          const int32_t *ids, int64_t ids_stride_bytes,
@@ -244,6 +245,7 @@ typedef struct mi355q_attn {
     float          scale;
     float         *out;
     const int32_t *n_kv_dev;         /* optional, device: the window length of THIS run (<= n_kv, which then is the maximum the plan is sized for) */
+    int64_t        q_id, k_id, v_id, out_id;   /* value ids (see mi355q_stage); 0 = identify by address */
 } mi355q_attn;
 typedef struct mi355q_stage {
     mi355q_mat   mats[4];    /* GEMV: y_stride is unused (one activation row) */
@@ -260,7 +262,21 @@ typedef struct mi355q_stage {
     const float *norm_w;     /* X_NORM: optional weight vector [k] (complete before the launch)        */
     float       *sum_out;    /* X_NORM with x1: where t = x0 + x1 is stored (the next residual's operand), optional */
     const mi355q_attn *attn; /* MI355Q_STAGE_ATTN */
+    /* VALUE IDS (optional, 0 = unused).  By default an operand is matched to the earlier output whose ADDRESS range contains it.  A caller
+     * whose allocator hands the same memory to several intermediates of one graph (ggml_gallocr does: K's projection reuses the dead pre-rope
+     * Q's block, V's reuses K's) cannot be matched that way once the plan reorders consumers behind later producers.  Such a caller labels
+     * every output with a unique non-zero id (y_id[i] for mats[i].y, sum_id for sum_out, attn->out_id) and every operand with the id of the
+     * value it means (x_id, x1_id, attn->q_id / k_id / v_id; 0 = a plain vector complete before the launch): ids then decide, addresses
+     * only give the offset of a sub-vector inside the labelled output.                                                                       */
+    int64_t      y_id[4], sum_id, x_id, x1_id;
+    /* OUTPUT FORM.  MI355Q_Y_ROWS (0): y_i = W_i . x, one vector per matrix.  MI355Q_Y_UNARY_MUL: n_mats == 2, same type and m; the stage
+     * publishes ONE vector  y = unary(W_0 . x) * (W_1 . x)  of m elements at mats[0].y (id y_id[0]; mats[1].y is unused): UNARY -> MUL of
+     * build_ffn (LLM_FFN_SILU + LLM_FFN_PAR) folded into the producer, so that ffn_down gathers one vector instead of two.  Every workgroup
+     * computes matching rows of both matrices; same f32 expressions as mi355q_op_unary_mul.                                                   */
+    int          y_kind, y_unary;
 } mi355q_stage;
+#define MI355Q_Y_ROWS      0
+#define MI355Q_Y_UNARY_MUL 1
 typedef struct mi355q_plan mi355q_plan;
 int     mi355q_plan_create(mi355q_plan **out, const mi355q_stage *stages, int n_stages, int flags);
 int     mi355q_plan_run(mi355q_plan *plan, void *stream);
@@ -335,6 +351,11 @@ int mi355q_op_mul_mat_f(const mi355q_tensor *a, const mi355q_tensor *b, const mi
  * launch graph be replayed while the KV-cache store position moves every token (cf. ggml-cuda.cu cpy_dest_ptrs). */
 int mi355q_op_cpy_indirect(const mi355q_tensor *a, const mi355q_tensor *dst, void *const *dest_table, int index, void *stream);
 int mi355q_op_get_rows(const mi355q_tensor *a, const mi355q_tensor *ids, const mi355q_tensor *dst, void *stream);
+/* The MoE router ops of build_moe_ffn (src/llama-graph.cpp:824-965): GGML_OP_ARGSORT (ggml_top_k = argsort descending + a view of the first k):
+ * dst i32, same shape as a (f32), dst[row][r] = index of the element of rank r of the row (ties keep index order; ggml-cuda/argsort.cu:11, CPU
+ * ops.cpp ggml_compute_forward_argsort_f32); GGML_OP_SUM_ROWS: dst[0, i1, i2, i3] = sum_i0 a[i0, i1, i2, i3], accumulated in f64 as the CPU does. */
+int mi355q_op_argsort(const mi355q_tensor *a, const mi355q_tensor *dst, int descending, void *stream);
+int mi355q_op_sum_rows(const mi355q_tensor *a, const mi355q_tensor *dst, void *stream);
 int mi355q_op_scale(const mi355q_tensor *a, const mi355q_tensor *dst, float scale, void *stream);
 
 /* ---- launch graphs: capture everything enqueued on `stream` between begin and end, replay it with one call ---------------

@@ -47,11 +47,13 @@ struct mi355_plan_entry {               // a decode plan cached per graph key (d
     int n_stages = 0;
 };
 struct mi355_device_ctx {
-    int         index;
+    int         index;         // HIP device ordinal (MI355_DUP_DEVICES exposes one physical device under several names: same ordinal)
     std::string name;          // "MI355_0"
     std::string description;
     struct ggml_backend_buffer_type buft;
     std::string buft_name;
+    struct ggml_backend_buffer_type host_buft;     // pinned host memory (get_host_buffer_type)
+    std::string host_buft_name;
 };
 
 struct mi355_buffer_ctx {
@@ -63,6 +65,7 @@ struct mi355_backend_ctx {
     int         device;
     std::string name;
     void *      stream    = nullptr;
+    void *      copy_event = nullptr;   // orders a peer copy issued on THIS backend's stream before the destination backend's stream
     void *      workspace = nullptr;
     size_t      workspace_size = 0;
     // launch-graph cache of the last compute graph (the reference's counterpart: ggml-cuda.cu:2470-2781)
@@ -268,7 +271,7 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, struct ggml_tensor * dst) 
     const struct ggml_tensor * ids = dst->src[2];
     const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
     const int64_t n_used = ids->ne[0], n_tok = ids->ne[1], b_ne1 = b->ne[1];
-    const size_t  ws = mi355q_mul_mat_id_workspace((int) as->type, M, K, n_used, n_tok, b_ne1);
+    const size_t  ws = mi355q_mul_mat_id_workspace((int) as->type, M, K, n_used, n_tok, b_ne1, n_expert);
     void * wsp = ws ? mi355_workspace(ctx, ws) : nullptr;
     MQ_CHECK(mi355q_mul_mat_id((int) as->type, as->data, (int64_t) as->nb[1], (int64_t) as->nb[2], n_expert,
                                (const float *) b->data, b_ne1, (int64_t) b->nb[1], (int64_t) b->nb[2],
@@ -283,6 +286,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
     if (ctx->stream) { mi355q_stream_synchronize(ctx->stream); mi355q_stream_destroy(ctx->stream); }
+    if (ctx->copy_event) mi355q_event_destroy(ctx->copy_event);
     if (ctx->workspace) mi355q_free(ctx->workspace);
     if (getenv("MI355_GRAPH_STATS")) {
         fprintf(stderr, "MI355 graph_compute calls: %ld eager, %ld captured, %ld replayed\n", ctx->n_eager, ctx->n_captured, ctx->n_replayed);
@@ -376,6 +380,13 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int
         float sc; memcpy(&sc, dst->op_params, sizeof(float));
         MQ_CHECK(mi355q_op_scale(&a, &d, sc, ctx->stream));
     } break;
+    case GGML_OP_ARGSORT: {                                   // op_params[0]: GGML_SORT_ORDER_ASC (0) / _DESC (1); dst is i32 (4-byte elements, same strides)
+        mi355q_tensor di = d; di.type = MI355Q_T_F32;
+        MQ_CHECK(mi355q_op_argsort(&a, &di, ((const int32_t *) dst->op_params)[0] == GGML_SORT_ORDER_DESC, ctx->stream));
+    } break;
+    case GGML_OP_SUM_ROWS:
+        MQ_CHECK(mi355q_op_sum_rows(&a, &d, ctx->stream));
+        break;
     case GGML_OP_ROPE: {
         mi355q_rope_params p;
         const int32_t * q = (const int32_t *) dst->op_params;
@@ -392,29 +403,35 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int
     }
 }
 
-// everything a captured launch depends on, EXCEPT the destination pointer of CPY nodes (read from dest_table on the device)
+// everything a captured launch / a decode plan depends on, EXCEPT the destination pointer of CPY nodes (read from dest_table on the device)
 static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph) {
     uint64_t h = 1469598103934665603ull;
-    // hashed a 64-bit word at a time: a token's graph is ~1000 nodes x ~250 bytes and this runs on every graph_compute
+    // A token's graph is ~1000 nodes and this runs on every graph_compute: per node only what a launch can depend on is mixed in, a 64-bit word
+    // at a time -- the node's op, parameters, type, shape, strides and address, and per operand its address, type and shape (an operand's strides
+    // are those of its own node, or of a leaf whose address and shape fix them).
+    auto mix64 = [&](uint64_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
     auto mix = [&](const void * p, size_t n) {
         const uint8_t * b = (const uint8_t *) p;
-        for (; n >= 8; n -= 8, b += 8) { uint64_t w; memcpy(&w, b, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
-        if (n) { uint64_t w = 0; memcpy(&w, b, n); w |= (uint64_t) n << 56; h =(h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
-    };
-    auto mix_tensor = [&](const struct ggml_tensor * t, bool with_data) {
-        if (!t) { const int z = 0; mix(&z, sizeof(z)); return; }
-        mix(&t->type, sizeof(t->type)); mix(t->ne, sizeof(t->ne)); mix(t->nb, sizeof(t->nb));
-        if (with_data) mix(&t->data, sizeof(t->data));
+        for (; n >= 8; n -= 8, b += 8) { uint64_t w; memcpy(&w, b, 8); mix64(w); }
+        if (n) { uint64_t w = 0; memcpy(&w, b, n); mix64(w | ((uint64_t) n << 56)); }
     };
     for (int i = 0; i < cgraph->n_nodes; ++i) {
         const struct ggml_tensor * n = cgraph->nodes[i];
         // views / reshapes launch nothing: what they describe reaches the key through the nodes that consume them (a view into the KV
         // cache at the store position moves every token and must not invalidate the capture)
         if (n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE) continue;
-        mix(&n->op, sizeof(n->op)); mix(n->op_params, sizeof(n->op_params));
         const bool cpy = n->op == GGML_OP_CPY;
-        mix_tensor(n, !cpy);
-        for (int j = 0; j < GGML_MAX_SRC; ++j) mix_tensor(n->src[j], !(cpy && j == 1));
+        mix64(((uint64_t) n->op << 32) | (uint64_t) n->type);
+        mix(n->op_params, sizeof(n->op_params));
+        mix(n->ne, sizeof(n->ne)); mix(n->nb, sizeof(n->nb));
+        if (!cpy) mix64((uint64_t) (uintptr_t) n->data);
+        for (int j = 0; j < GGML_MAX_SRC; ++j) {
+            const struct ggml_tensor * t = n->src[j];
+            if (!t) { mix64(0x5bd1e995u + (uint64_t) j); continue; }
+            mix64(((uint64_t) t->type << 32) ^ (uint64_t) j);
+            mix(t->ne, sizeof(t->ne)); mix(t->nb, sizeof(t->nb));
+            if (!(cpy && j == 1)) mix64((uint64_t) (uintptr_t) t->data);
+        }
     }
     return h;
 }
@@ -626,6 +643,7 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
         } break;
         case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
         case GGML_OP_DUP: case GGML_OP_SOFT_MAX: case GGML_OP_ROPE: case GGML_OP_GET_ROWS: case GGML_OP_SCALE: case GGML_OP_FLASH_ATTN_EXT:
+        case GGML_OP_ARGSORT: case GGML_OP_SUM_ROWS:
             mi355_glue_op(ctx, node); break;
         default:
             GGML_LOG_ERROR("MI355: op %s reached graph_compute but supports_op never accepts it\n", ggml_op_name(node->op));
@@ -646,9 +664,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
     static const bool env_no_plan = getenv("MI355_NO_PLAN") != nullptr;
     bool try_graphs = !env_off && !ctx->graphs_disabled && cgraph->n_nodes >= 8;
     const bool try_plan = !env_no_plan && !ctx->plans_disabled && cgraph->n_nodes >= 8;
-    // a prefill-sized MUL_MAT_ID groups its rows by expert on the host (a stream synchronize inside): such a graph cannot be captured
-    for (int i = 0; try_graphs && i < cgraph->n_nodes; ++i)
-        if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT_ID && cgraph->nodes[i]->src[2]->ne[0] * cgraph->nodes[i]->src[2]->ne[1] >= 17) try_graphs = false;
+    // (MUL_MAT_ID groups its rows by expert on the device at every size: such graphs are capturable too)
 
     // destination pointers of the CPY nodes of THIS call
     int n_cpy = 0;
@@ -732,20 +748,90 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
     return st;
 }
 
+// ---- asynchronous tensor access, copies between backends and events (the --split-mode layer hop) ----------------------------
+// Reference counterparts: ggml-cuda.cu:2360-2460 (set / get / cpy_tensor_async), :2784-2810 (event_record / event_wait), ggml-backend.cpp:1355-1445
+// (how ggml_backend_sched uses them between splits).  Plain (non-quantized or canonical-layout) tensors are copied on the backend's stream;
+// planar quantized rows need the layout conversion and take the synchronous buffer path.
+static bool mi355_backend_is_ours(ggml_backend_t b) { return b && b->iface.get_name == mi355_backend_get_name; }
+
+static void mi355_backend_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    struct ggml_backend_buffer * buf = tensor->view_src ? tensor->view_src->buffer : tensor->buffer;
+    GGML_ASSERT(mi355_buffer_is_ours(buf) && "unsupported buffer type");
+    mi355q_set_device(ctx->device);
+    if (mi355_rows_planar(tensor)) {                              // (weights are uploaded once, at load time)
+        MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+        mi355_buffer_transfer((mi355_buffer_ctx *) buf->context, tensor, (void *) data, offset, size, true);
+        return;
+    }
+    MQ_CHECK(mi355q_memcpy_h2d((char *) tensor->data + offset, data, size, ctx->stream));
+}
+
+static void mi355_backend_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    struct ggml_backend_buffer * buf = tensor->view_src ? tensor->view_src->buffer : tensor->buffer;
+    GGML_ASSERT(mi355_buffer_is_ours(buf) && "unsupported buffer type");
+    mi355q_set_device(ctx->device);
+    if (mi355_rows_planar(tensor)) {
+        MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
+        mi355_buffer_transfer((mi355_buffer_ctx *) buf->context, tensor, data, offset, size, false);
+        return;
+    }
+    MQ_CHECK(mi355q_memcpy_d2h(data, (const char *) tensor->data + offset, size, ctx->stream));
+}
+
+// dst (in a buffer of backend_dst's device) = src (in a buffer of backend_src's device), without a host round trip and without blocking the
+// host: the copy is enqueued on the SOURCE stream (behind the kernels that produce src), an event marks its end and the DESTINATION stream waits
+// for that event -- hipMemcpyPeerAsync over xGMI between two devices, a device-to-device copy when both backends drive the same device.
+static bool mi355_backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (!mi355_backend_is_ours(backend_src) || !mi355_backend_is_ours(backend_dst)) return false;
+    struct ggml_backend_buffer * bs = src->view_src ? src->view_src->buffer : src->buffer;
+    struct ggml_backend_buffer * bd = dst->view_src ? dst->view_src->buffer : dst->buffer;
+    if (!mi355_buffer_is_ours(bs) || !mi355_buffer_is_ours(bd)) return false;
+    if (mi355_is_quant(src->type) && mi355_root(src)->ne[0] != mi355_root(dst)->ne[0]) return false;   // (device rows of another row length are laid out differently)
+    mi355_backend_ctx * cs = (mi355_backend_ctx *) backend_src->context, * cd = (mi355_backend_ctx *) backend_dst->context;
+    const int dev_s = ((mi355_buffer_ctx *) bs->context)->device, dev_d = ((mi355_buffer_ctx *) bd->context)->device;
+    if (dev_s != cs->device || dev_d != cd->device) return false;
+    const size_t bytes = ggml_nbytes(src);                        // (same layout asserted by the caller: ggml_backend_tensor_copy_async)
+    mi355q_set_device(cs->device);
+    if (backend_src == backend_dst) {
+        MQ_CHECK(mi355q_memcpy_d2d(dst->data, src->data, bytes, cs->stream));
+        return true;
+    }
+    MQ_CHECK(mi355q_memcpy_peer(dst->data, dev_d, src->data, dev_s, bytes, cs->stream));
+    if (!cs->copy_event) MQ_CHECK(mi355q_event_create(&cs->copy_event));
+    MQ_CHECK(mi355q_event_record(cs->copy_event, cs->stream));
+    mi355q_set_device(cd->device);
+    MQ_CHECK(mi355q_event_wait(cd->stream, cs->copy_event));
+    return true;
+}
+
+static void mi355_backend_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    mi355q_set_device(ctx->device);
+    MQ_CHECK(mi355q_event_record(event->context, ctx->stream));
+}
+
+static void mi355_backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
+    mi355q_set_device(ctx->device);
+    MQ_CHECK(mi355q_event_wait(ctx->stream, event->context));
+}
+
 static const struct ggml_backend_i mi355_backend_iface = {
     /* .get_name           = */ mi355_backend_get_name,
     /* .free               = */ mi355_backend_free,
-    /* .set_tensor_async   = */ nullptr,
-    /* .get_tensor_async   = */ nullptr,
-    /* .cpy_tensor_async   = */ nullptr,
+    /* .set_tensor_async   = */ mi355_backend_set_tensor_async,
+    /* .get_tensor_async   = */ mi355_backend_get_tensor_async,
+    /* .cpy_tensor_async   = */ mi355_backend_cpy_tensor_async,
     /* .synchronize        = */ mi355_backend_synchronize,
     /* .graph_plan_create  = */ nullptr,
     /* .graph_plan_free    = */ nullptr,
     /* .graph_plan_update  = */ nullptr,
     /* .graph_plan_compute = */ nullptr,
     /* .graph_compute      = */ mi355_backend_graph_compute,
-    /* .event_record       = */ nullptr,
-    /* .event_wait         = */ nullptr,
+    /* .event_record       = */ mi355_backend_event_record,
+    /* .event_wait         = */ mi355_backend_event_wait,
 };
 
 // ------------------------------------------------------------------------------------------------ device
@@ -766,7 +852,7 @@ static void mi355_dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_
     props->description = mi355_dev_get_description(dev);
     props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
     mi355_dev_get_memory(dev, &props->memory_free, &props->memory_total);
-    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false };
+    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ false, /* events */ true };
 }
 
 static ggml_backend_t mi355_dev_init_backend(ggml_backend_dev_t dev, const char * params) {
@@ -859,6 +945,14 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
         const struct ggml_tensor * a = op->src[0];
         return a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && mi355_operand_ok(a);
     }
+    case GGML_OP_ARGSORT: {                                   // the MoE router's top-k (ggml_top_k = argsort desc + view)
+        const struct ggml_tensor * a = op->src[0];
+        return a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_I32 && mi355_operand_ok(a) && op->nb[0] == sizeof(int32_t) && a->ne[0] <= 32768;
+    }
+    case GGML_OP_SUM_ROWS: {
+        const struct ggml_tensor * a = op->src[0];
+        return a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && mi355_operand_ok(a);
+    }
     case GGML_OP_ROPE: {
         const struct ggml_tensor * a = op->src[0];
         const int mode = ((const int32_t *) op->op_params)[2];
@@ -891,6 +985,56 @@ static bool mi355_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_
     return mi355_buft_is_ours(buft) && buft->device == dev;
 }
 
+// ---- pinned host buffer type (ggml-backend-impl.h:137-185 get_host_buffer_type; ggml-cuda.cu:1050-1110): staging memory the DMA engines read directly
+static const char * mi355_host_buft_get_name(ggml_backend_buffer_type_t buft) { return ((mi355_device_ctx *) buft->device->context)->host_buft_name.c_str(); }
+static void mi355_host_buffer_free(ggml_backend_buffer_t buffer) { mi355q_host_free(buffer->context); }
+static ggml_backend_buffer_t mi355_host_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    mi355_device_ctx * dev = (mi355_device_ctx *) buft->device->context;
+    mi355q_set_device(dev->index);
+    void * ptr = nullptr;
+    if (mi355q_host_malloc(&ptr, size + 64) != MI355Q_OK) return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size);   // (pageable memory still works)
+    ggml_backend_buffer_t buffer = ggml_backend_cpu_buffer_from_ptr(ptr, size);     // host memory behaves like a CPU buffer in every other respect
+    buffer->buft = buft;
+    buffer->iface.free_buffer = mi355_host_buffer_free;
+    return buffer;
+}
+static size_t mi355_host_buft_get_alignment(ggml_backend_buffer_type_t buft) { GGML_UNUSED(buft); return 64; }
+static bool mi355_host_buft_is_host(ggml_backend_buffer_type_t buft) { GGML_UNUSED(buft); return true; }
+static const struct ggml_backend_buffer_type_i mi355_host_buft_iface = {
+    /* .get_name       = */ mi355_host_buft_get_name,
+    /* .alloc_buffer   = */ mi355_host_buft_alloc_buffer,
+    /* .get_alignment  = */ mi355_host_buft_get_alignment,
+    /* .get_max_size   = */ nullptr,
+    /* .get_alloc_size = */ nullptr,
+    /* .is_host        = */ mi355_host_buft_is_host,
+};
+static ggml_backend_buffer_type_t mi355_dev_get_host_buffer_type(ggml_backend_dev_t dev) { return &((mi355_device_ctx *) dev->context)->host_buft; }
+
+// an op whose weights live in host memory is worth running here when the batch is large (the weights then cross PCIe once per batch):
+// the reference's rule, ggml-cuda.cu:3285-3291
+static bool mi355_dev_offload_op(ggml_backend_dev_t dev, const struct ggml_tensor * op) {
+    GGML_UNUSED(dev);
+    const int64_t batch = op->op == GGML_OP_MUL_MAT_ID ? op->ne[2] : (op->op == GGML_OP_GET_ROWS ? 0 : op->ne[1]);
+    return batch >= 32;
+}
+
+static ggml_backend_event_t mi355_dev_event_new(ggml_backend_dev_t dev) {
+    mi355_device_ctx * dctx = (mi355_device_ctx *) dev->context;
+    mi355q_set_device(dctx->index);
+    void * ev = nullptr;
+    if (mi355q_event_create(&ev) != MI355Q_OK) return nullptr;
+    return new ggml_backend_event{ /* .device = */ dev, /* .context = */ ev };
+}
+static void mi355_dev_event_free(ggml_backend_dev_t dev, ggml_backend_event_t event) {
+    mi355q_set_device(((mi355_device_ctx *) dev->context)->index);
+    mi355q_event_destroy(event->context);
+    delete event;
+}
+static void mi355_dev_event_synchronize(ggml_backend_dev_t dev, ggml_backend_event_t event) {
+    mi355q_set_device(((mi355_device_ctx *) dev->context)->index);
+    MQ_CHECK(mi355q_event_synchronize(event->context));
+}
+
 static const struct ggml_backend_device_i mi355_device_iface = {
     /* .get_name             = */ mi355_dev_get_name,
     /* .get_description      = */ mi355_dev_get_description,
@@ -899,14 +1043,14 @@ static const struct ggml_backend_device_i mi355_device_iface = {
     /* .get_props            = */ mi355_dev_get_props,
     /* .init_backend         = */ mi355_dev_init_backend,
     /* .get_buffer_type      = */ mi355_dev_get_buffer_type,
-    /* .get_host_buffer_type = */ nullptr,
+    /* .get_host_buffer_type = */ mi355_dev_get_host_buffer_type,
     /* .buffer_from_host_ptr = */ nullptr,
     /* .supports_op          = */ mi355_dev_supports_op,
     /* .supports_buft        = */ mi355_dev_supports_buft,
-    /* .offload_op           = */ nullptr,
-    /* .event_new            = */ nullptr,
-    /* .event_free           = */ nullptr,
-    /* .event_synchronize    = */ nullptr,
+    /* .offload_op           = */ mi355_dev_offload_op,
+    /* .event_new            = */ mi355_dev_event_new,
+    /* .event_free           = */ mi355_dev_event_free,
+    /* .event_synchronize    = */ mi355_dev_event_synchronize,
 };
 
 // ------------------------------------------------------------------------------------------------ registry
@@ -944,18 +1088,24 @@ ggml_backend_reg_t ggml_backend_mi355_reg(void) {
     std::lock_guard<std::mutex> lock(mutex);
     if (!initialized) {
         mi355_reg_ctx * ctx = new mi355_reg_ctx;
-        int n = mi355q_device_count();
-        if (n > MI355_MAX_DEVICES) n = MI355_MAX_DEVICES;
-        for (int i = 0; i < n; ++i) {
+        int n_phys = mi355q_device_count();
+        if (n_phys > MI355_MAX_DEVICES) n_phys = MI355_MAX_DEVICES;
+        // MI355_DUP_DEVICES=k (testing): every physical device appears under k names, so that the scheduler's multi-device path (layer split,
+        // cpy_tensor_async, events) can be exercised on a one-GPU box; the duplicates drive the same HIP device through their own streams
+        int dup = 1;
+        if (const char * e = getenv("MI355_DUP_DEVICES")) { dup = atoi(e); if (dup < 1) dup = 1; if (dup * n_phys > MI355_MAX_DEVICES) dup = MI355_MAX_DEVICES / (n_phys > 0 ? n_phys : 1); }
+        for (int i = 0; i < n_phys * dup; ++i) {
             mi355_device_ctx * dctx = new mi355_device_ctx;
-            dctx->index = i;
+            dctx->index = i / dup;
             dctx->name = "MI355_" + std::to_string(i);
             char desc[256] = "AMD Instinct MI355X";
-            mi355q_device_info(i, desc, sizeof(desc), nullptr, nullptr, nullptr);
+            mi355q_device_info(dctx->index, desc, sizeof(desc), nullptr, nullptr, nullptr);
             dctx->description = desc;
             dctx->buft_name = dctx->name;
+            dctx->host_buft_name = dctx->name + "_Host";
             ggml_backend_device * dev = new ggml_backend_device{ /* .iface = */ mi355_device_iface, /* .reg = */ &reg, /* .context = */ dctx };
             dctx->buft = { /* .iface = */ mi355_buft_iface, /* .device = */ dev, /* .context = */ nullptr };
+            dctx->host_buft = { /* .iface = */ mi355_host_buft_iface, /* .device = */ dev, /* .context = */ nullptr };
             ctx->devices.push_back(dev);
         }
         reg = { /* .api_version = */ GGML_BACKEND_API_VERSION, /* .iface = */ mi355_reg_iface, /* .context = */ ctx };

@@ -23,11 +23,11 @@ int launch_pack(int type, void * dst, const void * src, int64_t nrows, int64_t k
 bool mmq_supported(int type, int64_t k);
 size_t mmq_workspace(int64_t n, int64_t k);
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                    int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare);
+                    int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare, const MoeTiles * moe = nullptr);
 size_t mmq_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu);
 bool mmq_i8_supported(int type, int64_t k);
 int launch_mmq_i8_multi(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
-                        void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare);
+                        void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare, const MoeTiles * moe = nullptr);
 size_t mmq_i8_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu);
 
 // tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
@@ -59,25 +59,75 @@ static int cu_count() {
 static int64_t moe_align256(int64_t v) { return (v + 255) & ~(int64_t) 255; }
 extern "C" size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k);
 
-// ---- grouped MUL_MAT_ID (many (token, slot) pairs): rows gathered by expert, one ordinary matmul per expert, rows scattered back ----
-// xg[i][:] = x[tok(order[i])][slot(order[i]) % x_ne1][:]        (order = pair indices sorted by expert)
+// ---- grouped MUL_MAT_ID (many (token, slot) pairs), entirely on the device -------------------------------------------------------------
+// The reference groups the rows of a batch by expert on the HOST (CPU backend: ggml-cpu.c:1628-1643; CUDA backend: ids copied to the host with a
+// stream synchronize, ggml-cuda.cu:2008-2011) and multiplies expert by expert.  Here one workgroup counting-sorts the pairs by expert into
+// segments aligned to the matrix-core token tile, the rows are gathered in that order, ONE launch of the prefill tier walks all token tiles
+// (each tile knows its expert, csrc/mi355q_common.h MoeTiles) and the rows are scattered back: no host round trip, so the graph stays
+// capturable, and an expert with few rows no longer costs a launch of its own.
+//   order[slot]        pair index of the gathered row, -1 for padding        slot_of_pair[p]  where pair p went, -1 for an invalid expert id
+//   seg_end[e]         one past the last slot of expert e                   tile_expert[t]   expert of token tile t, -1 beyond the last segment
+__global__ void __launch_bounds__(1024) k_moe_sort(const char * __restrict__ ids, int64_t ids_stride, int n_used, int pairs, int n_expert, int tile, int n_slots,
+                                                   int32_t * __restrict__ order, int32_t * __restrict__ slot_of_pair, int32_t * __restrict__ seg_end,
+                                                   int32_t * __restrict__ tile_expert) {
+    extern __shared__ int moe_lds[];                          // cnt[n_expert], cur[n_expert]
+    int * cnt = moe_lds, * cur = moe_lds + n_expert;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n_expert; e += 1024) cnt[e] = 0;
+    for (int i = tid; i < n_slots; i += 1024) order[i] = -1;
+    for (int t = tid; t < n_slots / tile; t += 1024) tile_expert[t] = -1;
+    __syncthreads();
+    auto expert_of = [&](int p) { const int t = p / n_used, u = p - t * n_used; return *(const int32_t *) (ids + (int64_t) t * ids_stride + 4 * u); };
+    for (int p = tid; p < pairs; p += 1024) { const int e = expert_of(p); if (e >= 0 && e < n_expert) atomicAdd(&cnt[e], 1); }
+    __syncthreads();
+    if (tid == 0) {                                           // segment starts: running sum, every segment aligned to the token tile (n_expert <= a few hundred)
+        int begin = 0;
+        for (int e = 0; e < n_expert; ++e) { cur[e] = begin; const int end = begin + cnt[e]; seg_end[e] = end; begin = (end + tile - 1) / tile * tile; }
+    }
+    __syncthreads();
+    for (int e = tid; e < n_expert; e += 1024) {
+        const int b = cur[e], en = seg_end[e];
+        for (int t = b / tile; t * tile < en; ++t) tile_expert[t] = e;
+    }
+    __syncthreads();                                          // (cur[] is read above as the segment start before it becomes the fill cursor)
+    for (int p = tid; p < pairs; p += 1024) {
+        const int e = expert_of(p);
+        int slot = -1;
+        if (e >= 0 && e < n_expert) { slot = atomicAdd(&cur[e], 1); order[slot] = p; }
+        slot_of_pair[p] = slot;
+    }
+}
+// xg[slot][:] = x[tok(order[slot])][slot_u(order[slot]) % x_ne1][:]      (padding slots are left as they are: their outputs are never stored)
 __global__ void __launch_bounds__(256) k_moe_gather(const char * __restrict__ x, int64_t x_stride1, int64_t x_stride2, int n_used, int x_ne1,
                                                     const int32_t * __restrict__ order, float * __restrict__ xg, int64_t k) {
-    const int p = order[blockIdx.x], t = p / n_used, u = p - t * n_used;
-    const float * src = (const float *) (x + (int64_t) t * x_stride2 + (int64_t) (u % x_ne1) * x_stride1);
-    float * dst = xg + (int64_t) blockIdx.x * k;
-    for (int64_t i = threadIdx.x; i < k; i += 256) dst[i] = src[i];
+    const int p = order[blockIdx.x];
+    if (p < 0) return;
+    const int t = p / n_used, u = p - t * n_used;
+    const float4 * src = (const float4 *) (x + (int64_t) t * x_stride2 + (int64_t) (u % x_ne1) * x_stride1);
+    float4 * dst = (float4 *) (xg + (int64_t) blockIdx.x * k);
+    for (int64_t i = threadIdx.x; i < k / 4; i += 256) dst[i] = src[i];
 }
-// y[order[i]][:] = yg[i][:]
-__global__ void __launch_bounds__(256) k_moe_scatter(const float * __restrict__ yg, const int32_t * __restrict__ order, float * __restrict__ y, int64_t m) {
-    const float * src = yg + (int64_t) blockIdx.x * m;
-    float * dst = y + (int64_t) order[blockIdx.x] * m;
+// y[p][:] = yg[slot_of_pair[p]][:]; a pair whose expert id is out of range gets NaN (the reference asserts on it; a device kernel cannot)
+__global__ void __launch_bounds__(256) k_moe_scatter(const float * __restrict__ yg, const int32_t * __restrict__ slot_of_pair, float * __restrict__ y, int64_t m) {
+    const int slot = slot_of_pair[blockIdx.x];
+    float * dst = y + (int64_t) blockIdx.x * m;
+    if (slot < 0) { for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = __int_as_float(0x7FC00000); return; }
+    const float * src = yg + (int64_t) slot * m;
     for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = src[i];
 }
-constexpr int64_t MOE_GROUPED_MIN_PAIRS = 17;      // below: one GEMV column per pair with the ids read on the device (no host round trip)
-static size_t moe_grouped_workspace(int type, int64_t m, int64_t k, int64_t pairs) {
-    // [order: pairs i32][xg: pairs x k f32][yg: pairs x m f32][scratch of the per-expert matmul, worst case all pairs on one expert]
-    return (size_t) (moe_align256(4 * pairs) + moe_align256(4 * pairs * k) + moe_align256(4 * pairs * m)) + mi355q_mul_mat_workspace(type, m, pairs, k);
+constexpr int64_t MOE_GROUPED_MIN_PAIRS = 17;      // below: one GEMV column per pair with the ids read on the device
+static int moe_tile(int64_t pairs, int64_t n_expert) { return pairs / (n_expert > 0 ? n_expert : 1) >= 192 ? 128 : 64; }
+static int64_t moe_slots(int64_t pairs, int64_t n_expert) {     // gathered rows incl. the alignment padding of every segment, a multiple of 128
+    const int tile = moe_tile(pairs, n_expert);
+    return (pairs + n_expert * (tile - 1) + 127) / 128 * 128;
+}
+static size_t moe_grouped_workspace(int type, int64_t m, int64_t k, int64_t pairs, int64_t n_expert) {
+    // [order: slots][slot_of_pair: pairs][seg_end: E][tile_expert: slots / 64] i32 | xg: slots x k f32 | yg: slots x m f32 | scratch of the prefill tier
+    const int64_t slots = moe_slots(pairs, n_expert);
+    return (size_t) (moe_align256(4 * (slots + pairs + n_expert + slots / 64)) + moe_align256(4 * slots * k) + moe_align256(4 * slots * m)) + mi355q_mul_mat_workspace(type, m, slots, k);
+}
+static bool moe_grouped_ok(int type, int64_t m, int64_t k, const void * x, int64_t x_stride1, int64_t x_stride2) {
+    return mmq_supported(type, k) && m % 4 == 0 && k % 4 == 0 && !(((uintptr_t) x | (uintptr_t) x_stride1 | (uintptr_t) x_stride2) & 15);
 }
 } // namespace mi355q
 
@@ -138,8 +188,24 @@ int mi355q_memcpy_d2d(void * d, const void * s, size_t n, void * st) { return co
 int mi355q_host_malloc(void ** p, size_t bytes) { HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocDefault)); return MI355Q_OK; }
 int mi355q_host_free(void * p) { HIP_TRY(hipHostFree(p)); return MI355Q_OK; }
 int mi355q_memcpy_peer(void * dst, int dst_device, const void * src, int src_device, size_t bytes, void * stream) {
-    if (dst_device == src_device) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream)); }
-    else                          { HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t) stream)); }
+    if (dst_device == src_device) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream)); return MI355Q_OK; }
+    // direct xGMI access between the two devices, enabled once per ordered pair (without it the runtime stages peer copies through the host)
+    static bool tried[64][64];
+    if (dst_device >= 0 && dst_device < 64 && src_device >= 0 && src_device < 64 && !tried[src_device][dst_device]) {
+        tried[src_device][dst_device] = tried[dst_device][src_device] = true;
+        int cur = 0, can = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int a = pass ? dst_device : src_device, b = pass ? src_device : dst_device;
+                if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can && hipSetDevice(a) == hipSuccess) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void) hipGetLastError();
+                }
+            }
+            (void) hipSetDevice(cur);
+        }
+    }
+    HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t) stream));
     return MI355Q_OK;
 }
 int mi355q_event_create(void ** e) { hipEvent_t h; HIP_TRY(hipEventCreateWithFlags(&h, hipEventDisableTiming)); *e = h; return MI355Q_OK; }
@@ -314,10 +380,10 @@ int mi355q_mul_mat(int type, const void * w, int64_t w_stride, const float * x, 
 }
 
 // ---- MUL_MAT_ID ----
-size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1) {
+size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1, int64_t n_expert) {
     const TypeInfo * t = type_info(type);
     if (!t || t->act < 0 || k % t->blck) return 0;
-    const size_t grouped = n_used * n_tok >= MOE_GROUPED_MIN_PAIRS ? moe_grouped_workspace(type, m, k, n_used * n_tok) : 0;
+    const size_t grouped = n_used * n_tok >= MOE_GROUPED_MIN_PAIRS && is_planar(t, k) && mmq_supported(type, k) && m % 4 == 0 ? moe_grouped_workspace(type, m, k, n_used * n_tok, n_expert < 1 ? 1 : (n_expert > 1024 ? 1024 : n_expert)) : 0;
     if (is_planar(t, k)) return grouped;
     const size_t generic = (size_t) align256(mi355q_row_size(t->act, k) * n_tok * x_ne1);
     return grouped > generic ? grouped : generic;
@@ -336,37 +402,31 @@ int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert
     if (pairs == 0 || m == 0) return MI355Q_OK;
     if (pairs > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat_id: more than 65535 (token,slot) pairs per call");
     hipStream_t st = (hipStream_t) stream;
-    if (pairs >= MOE_GROUPED_MIN_PAIRS) {
-        // Prefill-sized batches: the reference's grouped form -- rows are grouped by expert on the HOST (the CPU backend's row
-        // grouping, ggml-cpu.c:1628-1643; the CUDA backend copies the ids to the host the same way, ggml-cuda.cu mul_mat_id), every
-        // expert's rows are gathered into one contiguous block, multiplied by an ordinary mul_mat (GEMV tier up to 8 rows, the matrix-
-        // core tiers above) and scattered back.  One GEMV column per pair would re-stream an expert's weights once per pair.
-        if (!workspace || workspace_bytes < moe_grouped_workspace(type, m, k, pairs)) return fail(MI355Q_ERR_WORKSPACE, "mul_mat_id: workspace too small for the grouped form");
-        std::vector<int32_t> h_ids((size_t) pairs);
-        HIP_TRY(hipMemcpy2DAsync(h_ids.data(), (size_t) n_used * 4, ids, (size_t) ids_stride, (size_t) n_used * 4, (size_t) n_tok, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::vector<int32_t> count((size_t) n_expert + 1, 0), order((size_t) pairs);
-        for (int64_t p = 0; p < pairs; ++p) {
-            if (h_ids[(size_t) p] < 0 || h_ids[(size_t) p] >= n_expert) return fail(MI355Q_ERR_SHAPE, "mul_mat_id: expert id %d out of range", (int) h_ids[(size_t) p]);
-            ++count[(size_t) h_ids[(size_t) p] + 1];
-        }
-        for (int64_t e = 0; e < n_expert; ++e) count[(size_t) e + 1] += count[(size_t) e];          // -> first slot of each expert
-        { std::vector<int32_t> fill(count.begin(), count.end() - 1);
-          for (int64_t p = 0; p < pairs; ++p) order[(size_t) fill[(size_t) h_ids[(size_t) p]]++] = (int32_t) p; }
+    if (pairs >= MOE_GROUPED_MIN_PAIRS && is_planar(t, k) && n_expert <= 1024 && moe_grouped_ok(type, m, k, x, x_stride1, x_stride2) &&
+        !(((uintptr_t) w | (uintptr_t) w_stride | (uintptr_t) expert_stride) & 15)) {
+        // Prefill-sized batches: rows grouped by expert ON THE DEVICE, one launch of the matrix-core tier over all experts (see k_moe_sort)
+        const size_t need = moe_grouped_workspace(type, m, k, pairs, n_expert);
+        if (!workspace || workspace_bytes < need) return fail(MI355Q_ERR_WORKSPACE, "mul_mat_id: workspace %zu < %zu for the grouped form", workspace_bytes, need);
+        const int tile = moe_tile(pairs, n_expert);
+        const int64_t slots = moe_slots(pairs, n_expert);
         char * wsp = (char *) workspace;
-        int32_t * d_order = (int32_t *) wsp;                 wsp += moe_align256(4 * pairs);
-        float * xg = (float *) wsp;                           wsp += moe_align256(4 * pairs * k);
-        float * yg = (float *) wsp;                           wsp += moe_align256(4 * pairs * m);
+        int32_t * d_order = (int32_t *) wsp, * d_slot = d_order + slots, * d_seg_end = d_slot + pairs, * d_tile = d_seg_end + n_expert;
+        wsp += moe_align256(4 * (slots + pairs + n_expert + slots / 64));
+        float * xg = (float *) wsp;                           wsp += moe_align256(4 * slots * k);
+        float * yg = (float *) wsp;                           wsp += moe_align256(4 * slots * m);
         const size_t ws_left = workspace_bytes - (size_t) (wsp - (char *) workspace);
-        HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t) pairs * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));                    // (order.data() is pageable host memory that dies with this call)
-        hipLaunchKernelGGL(k_moe_gather, dim3((unsigned) pairs), dim3(256), 0, st, (const char *) x, x_stride1, x_stride2, (int) n_used, (int) x_ne1, d_order, xg, k);
-        for (int64_t e = 0; e < n_expert; ++e) {
-            const int64_t off = count[(size_t) e], cnt = count[(size_t) e + 1] - off;
-            if (cnt == 0) continue;
-            MQ_TRY(mi355q_mul_mat(type, (const char *) w + e * expert_stride, w_stride, xg + off * k, 4 * k, yg + off * m, 4 * m, m, cnt, k, wsp, ws_left, flags, stream));
+        hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(1024), (size_t) (2 * n_expert * 4), st, (const char *) ids, ids_stride, (int) n_used, (int) pairs, (int) n_expert, tile, (int) slots,
+                           d_order, d_slot, d_seg_end, d_tile);
+        hipLaunchKernelGGL(k_moe_gather, dim3((unsigned) slots), dim3(256), 0, st, (const char *) x, x_stride1, x_stride2, (int) n_used, (int) x_ne1, d_order, xg, k);
+        const MoeTiles mt = { d_tile, d_seg_end, expert_stride, tile, 0 };
+        static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
+        if (!no_i8 && mmq_i8_supported(type, k)) {
+            const mi355q_mat one = { type, w, w_stride, yg, 4 * m, m };
+            MQ_TRY(launch_mmq_i8_multi(&one, 1, xg, 4 * k, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
+        } else {
+            MQ_TRY(launch_mmq_bf16(type, w, w_stride, xg, 4 * k, yg, 4 * m, m, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
         }
-        hipLaunchKernelGGL(k_moe_scatter, dim3((unsigned) pairs), dim3(256), 0, st, yg, d_order, y, m);
+        hipLaunchKernelGGL(k_moe_scatter, dim3((unsigned) pairs), dim3(256), 0, st, yg, d_slot, y, m);
         return hipGetLastError() == hipSuccess ? MI355Q_OK : fail(MI355Q_ERR_HIP, "mul_mat_id: grouped launch failed");
     }
     if (is_planar(t, k) && gemv_fast_family(type) >= 0) {

@@ -181,7 +181,12 @@ k_gemv_fast(const GemvArgs a) {
     if (a.ids) {                                              // MoE: resolve this pair's expert on the device
         const int pair = (int) blockIdx.y, t = pair / a.n_used, u = pair - t * a.n_used;
         const int e = *(const int32_t *) ((const char *) a.ids + (int64_t) t * a.ids_stride + 4 * u);
-        if (e < 0 || e >= a.n_expert) return;                 // (the reference asserts; we leave the row untouched)
+        if (e < 0 || e >= a.n_expert) {                       // the reference asserts on such an id; on every device path the pair's row becomes NaN
+            const int rb = (int) blockIdx.x * (int) a.rows_per_wg, re = min(rb + (int) a.rows_per_wg, (int) a.total_rows);
+            float * yp = (float *) ((char *) a.mats[0].y + (int64_t) pair * a.total_rows * 4);
+            for (int r = rb + (int) threadIdx.x; r < re; r += GEMV_THREADS) yp[r] = __int_as_float(0x7FC00000);
+            return;
+        }
         xbase += (int64_t) t * a.x_stride2 + (int64_t) (u % a.x_ne1) * a.x_stride;
         w_off = (int64_t) e * a.expert_stride;
         y_off = (int64_t) pair * a.total_rows * 4;

@@ -231,7 +231,10 @@ k_gemv_generic(const uint8_t * __restrict__ w, int64_t w_stride, const uint8_t *
     if (moe.ids) {
         const int pair = (int) blockIdx.y, t = pair / moe.n_used, u = pair - t * moe.n_used;
         const int e = *(const int32_t *) ((const char *) moe.ids + (int64_t) t * moe.ids_stride + 4 * u);
-        if (e < 0 || e >= moe.n_expert) return;
+        if (e < 0 || e >= moe.n_expert) {                      // the reference asserts on such an id; on every device path the pair's row becomes NaN
+            for (int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x; row < m; row += (int64_t) gridDim.x * 256) yrow[row] = __int_as_float(0x7FC00000);
+            return;
+        }
         w += (int64_t) e * moe.expert_stride;
         n = (int64_t) t * moe.x_ne1 + (u % moe.x_ne1);         // activation row in the quantized workspace
     }

@@ -193,7 +193,8 @@ template <> struct W32<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]
 template <int T, int MMQ_BM, int MMQ_BN>
 __global__ void __launch_bounds__(MMQ_THREADS, (MMQ_BM == 64 && MMQ_BN == 64) ? 4 : 2)
 k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __restrict__ xb /* bf16 [n][k] */,
-           float * __restrict__ y, int64_t y_stride, int m, int n, int k, int n_split, int64_t split_stride /* floats between the partial outputs */) {
+           float * __restrict__ y, int64_t y_stride, int m, int n, int k, int n_split, int64_t split_stride /* floats between the partial outputs */,
+           const MoeTiles moe) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t * Ws = lds;
     uint8_t * Xs = lds + MMQ_BM * MMQ_LDS_STRIDE;                          // BN rows
@@ -202,6 +203,12 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
     constexpr int WM = MMQ_BM / 2, WN = MMQ_BN / 2, MT = WM / 16, NT = WN / 16;
     constexpr int UW = MMQ_BM * 4 / MMQ_THREADS, UX = MMQ_BN * 4 / MMQ_THREADS;
     const int m0 = blockIdx.x * MMQ_BM, n0 = blockIdx.y * MMQ_BN;
+    if (moe.tile_expert) {                                    // grouped MUL_MAT_ID: this token tile's expert (uniform per workgroup)
+        const int e = moe.tile_expert[n0 / moe.tile_tokens];
+        if (e < 0) return;
+        w += (int64_t) e * moe.expert_stride;
+        n = moe.seg_end[e];
+    }
     const int nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
     // split K (blockIdx.z): a shape whose 128 x 128 tiles do not fill the chip is cut along K instead of into smaller tiles (each weight is
     // then dequantized for 128 tokens, not 64); piece z writes its partial sums to y + z * split_stride, k_mmq_reduce adds them in order
@@ -341,7 +348,9 @@ size_t mmq_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu) {
 // w: planar device rows; x f32 [n][k] (row stride x_stride); workspace >= mmq_workspace(n,k); y f32 [n][m] (y_stride % 16 == 0)
 // `prepare` = convert the activations to bf16 first (matrices multiplied with the same activations share the copy)
 int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
-                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare) {
+                    float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare,
+                    const MoeTiles * moe_p = nullptr) {
+    MoeTiles moe = {}; if (moe_p) moe = *moe_p;
     if (!mmq_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (m <= 0 || n <= 0) return MI355Q_OK;
     if ((y_stride & 15) || ((uintptr_t) y & 15)) return MI355Q_ERR_ALIGN;
@@ -356,7 +365,8 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     if (2 * tiles(128, 128) >= 3 * (int64_t) n_cu) { bm = 128; bn = 128; }
     else if (tiles(128, 64) >= 2 * (int64_t) n_cu) { bm = 128; bn = 64; }
     // ... or 128 x 128 tiles on K pieces (partial sums behind the activation copy in the scratch buffer, added up by k_mmq_reduce)
-    int splits = mmq_bf16_splits(m, n, k, n_cu);
+    if (moe.tile_expert) { bm = 128; bn = moe.tile_tokens; }   // (grouped: the token tile the segments were aligned to)
+    int splits = moe.tile_expert ? 1 : mmq_bf16_splits(m, n, k, n_cu);
     const size_t part_off = mmq_workspace(n, k);
     if (splits > 1 && workspace_bytes < part_off + (size_t) splits * (size_t) n * (size_t) m * 4) splits = 1;
     float * yk = y; int64_t yk_stride = y_stride; int64_t split_stride = 0;
@@ -372,7 +382,7 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
             attr_set[dev_] = true;                                                                                                 \
         }                                                                                                                          \
         hipLaunchKernelGGL((k_mmq_bf16<T, BM, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,     \
-                           (const uint16_t *) workspace, yk, yk_stride, (int) m, (int) n, (int) k, splits, split_stride); }
+                           (const uint16_t *) workspace, yk, yk_stride, (int) m, (int) n, (int) k, splits, split_stride, moe); }
 #define MI355Q_MMQ_CASE(T) case T: if (bm == 128 && bn == 128) MI355Q_MMQ_LAUNCH(T, 128, 128) else if (bm == 128) MI355Q_MMQ_LAUNCH(T, 128, 64) else MI355Q_MMQ_LAUNCH(T, 64, 64) break;
     switch (type) {
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q5_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q6_K)

@@ -82,7 +82,7 @@ struct I8Mats { const uint8_t * w[4]; int64_t w_stride[4]; float * y[4]; int64_t
 template <int RT, int TT, bool STAMPS>
 __global__ void __launch_bounds__(256, 2)
 k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t * __restrict__ xs, const float * __restrict__ xd,
-             int n, int n_pad, int nb, int n_tok_tiles, int total_tiles, int per_xcd, int n_split, int64_t split_stride) {
+             int n, int n_pad, int nb, int n_tok_tiles, int total_tiles, int per_xcd, int n_split, int64_t split_stride, const MoeTiles moe) {
     constexpr int BN = 16 * TT, BM = 64 * RT;
     constexpr int XQ_BYTES = BN * I8Q_REC, XS_BYTES = BN * I8Q_XS, XD_BYTES = BN * 4, BUF = XQ_BYTES + XS_BYTES + XD_BYTES;
     constexpr int XQ_PIECES = XQ_BYTES / 1024, XS_PIECES = XS_BYTES / 1024;          // 1 KiB per wave-instruction (64 lanes x 16 B)
@@ -96,6 +96,12 @@ k_mmq_i8_q4k(const I8Mats mats, const uint8_t * __restrict__ xq, const uint8_t *
     // which matrix (scalar selects on kernel arguments; rb_begin of unused slots is INT_MAX)
     const int mi = (rb_all >= mats.rb_begin[1]) + (rb_all >= mats.rb_begin[2]) + (rb_all >= mats.rb_begin[3]);
     const uint8_t * __restrict__ w = mi == 0 ? mats.w[0] : mi == 1 ? mats.w[1] : mi == 2 ? mats.w[2] : mats.w[3];
+    if (moe.tile_expert) {                                    // grouped MUL_MAT_ID: this token tile's expert (uniform per workgroup)
+        const int e = moe.tile_expert[tt0 * (16 * TT) / moe.tile_tokens];
+        if (e < 0) return;
+        w += (int64_t) e * moe.expert_stride;
+        n = moe.seg_end[e];
+    }
     const int64_t w_stride = mi == 0 ? mats.w_stride[0] : mi == 1 ? mats.w_stride[1] : mi == 2 ? mats.w_stride[2] : mats.w_stride[3];
     float * __restrict__ y = mi == 0 ? mats.y[0] : mi == 1 ? mats.y[1] : mi == 2 ? mats.y[2] : mats.y[3];
     const int64_t y_stride = mi == 0 ? mats.y_stride[0] : mi == 1 ? mats.y_stride[1] : mi == 2 ? mats.y_stride[2] : mats.y_stride[3];
@@ -282,7 +288,8 @@ size_t mmq_i8_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu) {
 }
 
 int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
-                        void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare) {
+                        void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare, const MoeTiles * moe_p = nullptr) {
+    MoeTiles moe = {}; if (moe_p) moe = *moe_p;
     if (n_mats < 1 || n_mats > 4) return MI355Q_ERR_SHAPE;
     for (int i = 0; i < n_mats; ++i) if (!mmq_i8_supported(mt[i].type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (n <= 0) return MI355Q_OK;
@@ -297,7 +304,7 @@ int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int6
     // otherwise 64 x 64 (four times the workgroups, 3-4 per CU): measured at N = 512, 4096 x 4096: 47 -> 42 us, 4096 x 14336: 147 -> 128 us
     int64_t rb128 = 0; for (int i = 0; i < n_mats; ++i) rb128 += (mt[i].m + 127) / 128;
     // ... or, for a single matrix, 128 x 128 tiles over K pieces (partial sums behind the activation image, added up by k_mmq_reduce)
-    int splits = n_mats == 1 ? mmq_i8_splits(mt[0].m, n, k, n_cu) : 1;
+    int splits = n_mats == 1 && !moe.tile_expert ? mmq_i8_splits(mt[0].m, n, k, n_cu) : 1;
     const size_t part_off = mmq_i8_workspace(n, k);
     if (splits > 1 && (workspace_bytes < part_off + (size_t) splits * (size_t) n * (size_t) mt[0].m * 4 || (mt[0].y_stride & 15) || ((uintptr_t) mt[0].y & 15))) splits = 1;
     mi355q_mat part_mat;
@@ -325,10 +332,10 @@ int launch_mmq_i8_multi(const mi355q_mat * mt, int n_mats, const float * x, int6
         const int n_tok_tiles = (int) (n_pad / bn), total = rbs * n_tok_tiles, per_xcd = (total + 7) / 8;                         \
         if (total > 0)                                                                                                             \
             hipLaunchKernelGGL((k_mmq_i8_q4k<RT, TT, STAMPS>), dim3((unsigned) (8 * per_xcd), (unsigned) splits), dim3(256), lds_bytes, stream, im, \
-                               (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, (int) n, (int) n_pad, nb, n_tok_tiles, total, per_xcd, splits, split_stride); }
+                               (const uint8_t *) xq, (const uint8_t *) xs, (const float *) xd, (int) n, (int) n_pad, nb, n_tok_tiles, total, per_xcd, splits, split_stride, moe); }
     static const bool stamps = getenv("MI355Q_I8_STAMPS") != nullptr;       // dev: phase times of workgroup 0 into y[0][0..3] (tools/pp_shape.py)
     static const int force = getenv("MI355Q_I8_CFG") ? atoi(getenv("MI355Q_I8_CFG")) : 0;      // dev: 28 / 24 / 18 / 14 = RT, TT
-    const int cfg = force ? force : (wide ? 28 : 14);
+    const int cfg = force ? force : (moe.tile_expert ? (moe.tile_tokens == 128 ? 28 : 14) : (wide ? 28 : 14));   // (grouped: the tile the segments were aligned to)
     if (cfg == 28) { if (stamps) MI355Q_I8_LAUNCH(2, 8, true) else MI355Q_I8_LAUNCH(2, 8, false) }
     else if (cfg == 24) MI355Q_I8_LAUNCH(2, 4, false)
     else if (cfg == 18) MI355Q_I8_LAUNCH(1, 8, false)

@@ -572,6 +572,41 @@ __global__ void __launch_bounds__(256) k_get_rows(const TensorD a, const char * 
 }
 
 // ---- SCALE: dst = a * s   (ops.cpp:3840-3878, ggml_vec_scale_f32) -----------------------------------------------------
+// ---- ARGSORT (ggml-cpu/ops.cpp ggml_compute_forward_argsort_f32): dst[row][r] = index of the element of rank r.  One workgroup per row; the
+// row sits in LDS and element i finds its rank by counting the elements that sort before it (ties keep their index order) -- a row is the expert
+// scores of a token (8 .. 256 values), so the quadratic count is a handful of LDS reads per thread.
+__global__ void __launch_bounds__(256) k_argsort(const TensorD a, const TensorD d, int desc) {
+    extern __shared__ float row[];
+    const int64_t r = blockIdx.x, n = a.ne[0];
+    const int64_t i1 = r % a.ne[1], r2 = r / a.ne[1], i2 = r2 % a.ne[2], i3 = r2 / a.ne[2];
+    const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+    int32_t * dst = (int32_t *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    for (int64_t i = threadIdx.x; i < n; i += 256) row[i] = *(const float *) (src + i * a.nb[0]);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = row[i];
+        int rank = 0;
+        for (int64_t j = 0; j < n; ++j) {
+            const float w = row[j];
+            rank += desc ? (w > v || (w == v && j < i)) : (w < v || (w == v && j < i));
+        }
+        dst[rank] = (int32_t) i;
+    }
+}
+
+// ---- SUM_ROWS (ggml-cpu/ops.cpp ggml_compute_forward_sum_rows_f32: ggml_vec_sum_f32 accumulates in ggml_float = double): one wave per row
+__global__ void __launch_bounds__(256) k_sum_rows(const TensorD a, const TensorD d, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t i1 = r % a.ne[1], r2 = r / a.ne[1], i2 = r2 % a.ne[2], i3 = r2 / a.ne[2];
+    const char * src = a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+    double s = 0.0;
+    for (int64_t i = lane; i < a.ne[0]; i += 64) s += (double) *(const float *) (src + i * a.nb[0]);
+    s = wave_sum_f64(s);
+    if (lane == 0) *(float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = (float) s;
+}
+
 __global__ void __launch_bounds__(256) k_scale(const TensorD a, const TensorD d, float sc, int64_t n) {
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
         const int64_t i0 = i % d.ne[0], r = i / d.ne[0], i1 = r % d.ne[1], r2 = r / d.ne[1], i2 = r2 % d.ne[2], i3 = r2 / d.ne[2];
@@ -758,6 +793,32 @@ int mi355q_op_scale(const mi355q_tensor * a, const mi355q_tensor * dst, float sc
     const int64_t n = nelements(dst);
     if (n == 0) return MI355Q_OK;
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), scale, n);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_argsort(const mi355q_tensor * a, const mi355q_tensor * dst, int descending, void * stream) {
+    if (!a || !dst || !same_shape(a, dst) || a->type != 0) OPS_FAIL(MI355Q_ERR_SHAPE, "op_argsort: f32 source, i32 destination of the same shape");
+    if (dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_argsort: destination rows must be contiguous");
+    if (a->ne[0] > 32768) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_argsort: rows of more than 32768 elements");
+    const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
+    if (nrows == 0 || a->ne[0] == 0) return MI355Q_OK;
+    if (nrows > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_argsort: too many rows");
+    if (a->ne[0] * 4 > 48 * 1024) {
+        static bool big[64] = {};
+        int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
+        if (!big[dev]) { if (hipFuncSetAttribute((const void *) k_argsort, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "op_argsort: LDS attribute"); big[dev] = true; }
+    }
+    hipLaunchKernelGGL(k_argsort, dim3((unsigned) nrows), dim3(256), (size_t) a->ne[0] * 4, (hipStream_t) stream, to_d(a), to_d(dst), descending ? 1 : 0);
+    OPS_LAUNCHED();
+}
+
+int mi355q_op_sum_rows(const mi355q_tensor * a, const mi355q_tensor * dst, void * stream) {
+    if (!a || !dst || a->type != 0 || dst->type != 0 || dst->ne[0] != 1 || dst->ne[1] != a->ne[1] || dst->ne[2] != a->ne[2] || dst->ne[3] != a->ne[3])
+        OPS_FAIL(MI355Q_ERR_SHAPE, "op_sum_rows: f32 [ne0, ...] -> f32 [1, ...]");
+    const int64_t nrows = a->ne[1] * a->ne[2] * a->ne[3];
+    if (nrows == 0) return MI355Q_OK;
+    if ((nrows + 3) / 4 > 0x7FFFFFFF) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_sum_rows: too many rows");
+    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned) ((nrows + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), nrows);
     OPS_LAUNCHED();
 }
 

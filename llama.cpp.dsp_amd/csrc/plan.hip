@@ -36,7 +36,7 @@ constexpr int PLAN_D_MAX = 8;                     // ring depth (1-KiB steps in 
 __host__ __device__ constexpr int plan_depth(int type) {   // Q5_K / Q6_K slots carry qh too (1.5 KiB per step): 6 steps are the bytes of 8 Q4_K steps
     return (type == MI355Q_TYPE_Q5_K || type == MI355Q_TYPE_Q6_K) ? 6 : PLAN_D_MAX;
 }
-enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16 };
+enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32 };
 enum { PLAN_K_GEMV = 0, PLAN_K_ATTN = 1, PLAN_K_COMBINE = 2 };
 enum { PLAN_SYNC_ABORT = 0, PLAN_SYNC_WORDS = 32 };
 
@@ -55,7 +55,7 @@ struct AttnStage {
     const char * mask;
     Granule * part;                                // [n_head][n_split][head_dim + 2]  (o, m, l) of every split
     Granule * out_gran; float * out_plain;
-    int mask_f16, n_head, n_head_kv, hd, n_kv, n_split, per, plain;
+    int mask_f16, n_head, n_head_kv, hd, n_kv, n_split, per, plain, p_f16;
     float scale;
     // rope (ggml_rope_cache_init; see ops_glue.hip k_rope)
     int n_dims, neox; float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1;
@@ -75,6 +75,7 @@ struct alignas(64) PlanStage {
     const float *   norm_w;
     Granule *       sum_gran; float * sum_plain;
     const AttnStage * attn;
+    const AttnStage * next_attn;                  // the attention descriptor of the NEXT stage (prefetched with it), or null
     float           eps; int x_kind, x_unary; unsigned tag_off;
 };
 typedef const __attribute__((address_space(4))) PlanStage * StageC;   // descriptors are read with scalar loads
@@ -108,6 +109,12 @@ struct StageW {
         w0 = st->w[0]; w1 = st->w[1]; w2 = st->w[2]; w3 = st->w[3];
         ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = st->w_stride[2]; ws3 = st->w_stride[3];
         rb1 = st->row_begin[1]; rb2 = st->row_begin[2]; rb3 = st->row_begin[3];
+    }
+    // PAIRED stage (y = unary(W0 x) * (W1 x)): this workgroup's LOCAL rows [0, np) are rows p0.. of matrix 0, [np, 2 np) the same rows of matrix 1
+    __device__ __forceinline__ void load_paired(StageC st, int p0, int np) {
+        ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = ws3 = 0;
+        w0 = st->w[0] + (int64_t) p0 * ws0; w1 = st->w[1] + (int64_t) p0 * ws1; w2 = w3 = nullptr;
+        rb1 = np; rb2 = rb3 = 0x7FFFFFFF;
     }
     __device__ __forceinline__ void load_out(StageC st) {      // what the consumer needs (read after the prologue)
         y0 = st->y[0]; y1 = st->y[1]; y2 = st->y[2]; y3 = st->y[3]; g = st->yg;
@@ -164,7 +171,7 @@ __device__ __forceinline__ void publish(Granule * gp, float v, unsigned tag) {
 // consume this wave's rows of the stage; slot d holds item d, d+D, ... ; refills keep D items in flight
 template <int T, int D>
 __device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, const StageW & st, const StageGeom & g, int r_lo, int wave, int lane,
-                                         const ActView * av, unsigned tag, bool plain) {
+                                         const ActView * av, unsigned tag, bool plain, float * pair_lds) {
     // the consumers' lane-invariant state (LDS offsets, shifts) is derived from an opaque copy of the lane id HERE, so
     // that it cannot be computed (and kept live, and spilled) before the prologue
     int lane_c = lane; asm volatile("" : "+v"(lane_c));
@@ -178,8 +185,8 @@ __device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, cons
                 if (++cs_s == g.steps) {                      // row finished: reduce, publish (one granule), next row
                     const float t = wave_sum(acc[0]);
                     if (lane_c == 0) {
-                        publish(st.g + cs_gr, t, tag);
-                        if (plain) *st.y_ptr(cs_gr) = t;
+                        if (pair_lds) pair_lds[cs_gr] = t;    // PAIRED stage: the workgroup combines its rows after the loop
+                        else { publish(st.g + cs_gr, t, tag); if (plain) *st.y_ptr(cs_gr) = t; }
                     }
                     acc[0] = 0.0f; cs_s = 0; cs_gr += GEMV_WAVES;
                 }
@@ -274,17 +281,43 @@ __device__ __forceinline__ float unary_f(int uop, float x) {          // ops_glu
     return __fdiv_rn(1.0f, 1.0f + expf(-x));
 }
 
+// A pointer / value that is wave-uniform by construction but arrives in VGPRs (arguments of a non-inlined function): moved to SGPRs so that
+// everything read through it becomes scalar loads instead of per-lane global loads with their ~1 us dependent latencies.
+template <typename P> __device__ __forceinline__ P uniform_ptr(P p) {
+    const unsigned long long v = (unsigned long long) (uintptr_t) p;
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v), hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    return (P) (uintptr_t) (((unsigned long long) hi << 32) | lo);
+}
+
 struct StageCtx {
     uint8_t * lds; float * stg; int * ctl; double * part; unsigned * sync; unsigned long long timeout;
-    unsigned grid, epoch; int even, stage;
+    unsigned grid, epoch; int even, stage, image;     // image: bytes of the activation image at the start of the LDS allocation
+    const uint8_t * next_desc, * next_attn; unsigned pre_lds;   // the next stage's descriptors (global) and a 1-KiB LDS scratch area their lines are DMA-ed into
 };
+
+// Warm this XCD's L2 with the NEXT stage's descriptor while the current stage runs: descriptors are cold after every launch boundary and a
+// scalar load that misses to HBM costs ~1-2 us at the head of each of the ~200 stages of a token.  16 bytes per lane, global -> LDS with no VGPR
+// destination (the data is never read from there); untracked by the compiler's vmcnt bookkeeping, which can only make its waits longer.
+__device__ __forceinline__ void plan_prefetch_desc(const StageCtx & c, int wave, int lane) {
+    static_assert(sizeof(PlanStage) <= 32 * 16 && sizeof(AttnStage) <= 32 * 16, "descriptor prefetch covers 512 bytes each");
+    if (wave == GEMV_WAVES - 1 && c.next_desc != nullptr) {
+        const bool second = lane >= 32;                        // lanes 0..31: the stage descriptor; lanes 32..63: its attention descriptor, if any
+        const uint8_t * base = second ? c.next_attn : c.next_desc;
+        const int n16 = second ? (int) ((sizeof(AttnStage) + 15) / 16) : (int) ((sizeof(PlanStage) + 15) / 16);
+        if (base != nullptr && (lane & 31) < n16) {
+            const uint8_t * g = base + 16 * (lane & 31);
+            const unsigned dst = (unsigned) __builtin_amdgcn_readfirstlane((int) c.pre_lds);     // (wave-uniform by construction; the asm needs an SGPR)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(dst) : "memory");
+        }
+    }
+}
 enum { CTL_OK = 0 };
 
 // Gather the stage's activation vector t[k] (f32) into the LDS staging area: PLAIN t = x0, NORM t = x0 (+ x1), UNARY_MUL
 // t = unary(x0) * x1.  Chunks are dealt round-robin to the waves, two in flight per wave.  NORM: returns this wave's partial
 // sum of squares in `ssq`; the workgroup `sum_wg` also publishes t (the next residual's operand).  false = poll gave up.
 __device__ __forceinline__ bool plan_gather(StageC st, const StageCtx & c, int k, int wave, int lane, double & ssq) {
-    const int x_kind = st->x_kind, uop = st->x_unary;
+    const int x_kind = st->x_kind, uop = st->x_unary & 0xFF;
     const bool two = st->x1.plain != nullptr || st->x1.gran != nullptr;
     VecSrc v0, v1;
     v0.plain = st->x0.plain; v0.gran = st->x0.gran; v0.tag_off = st->x0.tag_off; v0.pad = 0;
@@ -297,40 +330,48 @@ __device__ __forceinline__ bool plan_gather(StageC st, const StageCtx & c, int k
     PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
     ssq = 0.0;
-#pragma unroll 1
-    for (int ch = wave; ch < chunks; ch += 2 * GEMV_WAVES) {
-        const int ch2 = ch + GEMV_WAVES;                       // second chunk of the pair (may be past the end: reads zeros, not checked)
-        float a0, a1, b0 = 0.f, b1 = 0.f, e0, e1, f0 = 0.f, f1 = 0.f;
-        for (;;) {
-            bool ok = src_try(s0, ch, lane, a0, a1) || 128 * ch + 2 * lane >= k;
-            bool ok2 = src_try(s0, ch2, lane, e0, e1) || 128 * ch2 + 2 * lane >= k;
-            if (two) {
-                ok  = (src_try(s1, ch, lane, b0, b1)  || 128 * ch + 2 * lane >= k) && ok;
-                ok2 = (src_try(s1, ch2, lane, f0, f1) || 128 * ch2 + 2 * lane >= k) && ok2;
+    // four 16-byte loads per lane are in flight per poll: two chunks of both operands, or four chunks of a single operand
+    // (a chunk past the end reads zeros through the bounded buffer resource and is not checked)
+    auto emit = [&](int cc, float p0, float p1, float q0, float q1) {
+        const int e = 128 * cc + 2 * lane;
+        if (e < k) {                                           // (k is even)
+            float t0, t1;
+            if (x_kind == MI355Q_X_UNARY_MUL) { t0 = __fmul_rn(unary_f(uop, p0), q0); t1 = __fmul_rn(unary_f(uop, p1), q1); }
+            else if (two)                     { t0 = __fadd_rn(p0, q0); t1 = __fadd_rn(p1, q1); }
+            else                              { t0 = p0; t1 = p1; }
+            if (x_kind == MI355Q_X_NORM) {
+                ssq += (double) __fmul_rn(t0, t0); ssq += (double) __fmul_rn(t1, t1);      // (ggml_float)(x*x): the square is rounded to f32 first
+                if (pub) {
+                    publish(st->sum_gran + e, t0, tag); publish(st->sum_gran + e + 1, t1, tag);
+                    if (st->flags & PLAN_F_SUM_PLAIN) { st->sum_plain[e] = t0; st->sum_plain[e + 1] = t1; }
+                }
             }
-            if (__ballot(!(ok && ok2)) == 0ull) break;
+            *(float2 *) (c.stg + e) = make_float2(t0, t1);
+        }
+    };
+    const int per_it = two ? 2 : 4;
+#pragma unroll 1
+    for (int ch = wave; ch < chunks; ch += per_it * GEMV_WAVES) {
+        float a0, a1, b0, b1, e0, e1, f0, f1;
+        const int c1 = ch + GEMV_WAVES, c2 = ch + 2 * GEMV_WAVES, c3 = ch + 3 * GEMV_WAVES;
+        for (;;) {
+            bool ok;
+            if (two) {
+                ok =       src_try(s0, ch, lane, a0, a1) || 128 * ch + 2 * lane >= k;
+                ok = (src_try(s1, ch, lane, b0, b1) || 128 * ch + 2 * lane >= k) && ok;
+                ok = (src_try(s0, c1, lane, e0, e1) || 128 * c1 + 2 * lane >= k) && ok;
+                ok = (src_try(s1, c1, lane, f0, f1) || 128 * c1 + 2 * lane >= k) && ok;
+            } else {
+                ok =       src_try(s0, ch, lane, a0, a1) || 128 * ch + 2 * lane >= k;
+                ok = (src_try(s0, c1, lane, b0, b1) || 128 * c1 + 2 * lane >= k) && ok;
+                ok = (src_try(s0, c2, lane, e0, e1) || 128 * c2 + 2 * lane >= k) && ok;
+                ok = (src_try(s0, c3, lane, f0, f1) || 128 * c3 + 2 * lane >= k) && ok;
+            }
+            if (__ballot(!ok) == 0ull) break;
             if (!poll_backoff(pc, spins, lane)) return false;
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = h ? ch2 : ch;
-            const int e = 128 * cc + 2 * lane;
-            if (e < k) {                                       // (k is even)
-                const float p0 = h ? e0 : a0, p1 = h ? e1 : a1, q0 = h ? f0 : b0, q1 = h ? f1 : b1;
-                float t0, t1;
-                if (x_kind == MI355Q_X_UNARY_MUL) { t0 = __fmul_rn(unary_f(uop, p0), q0); t1 = __fmul_rn(unary_f(uop, p1), q1); }
-                else if (two)                     { t0 = __fadd_rn(p0, q0); t1 = __fadd_rn(p1, q1); }
-                else                              { t0 = p0; t1 = p1; }
-                if (x_kind == MI355Q_X_NORM) {
-                    ssq += (double) __fmul_rn(t0, t0); ssq += (double) __fmul_rn(t1, t1);      // (ggml_float)(x*x): the square is rounded to f32 first
-                    if (pub) {
-                        publish(st->sum_gran + e, t0, tag); publish(st->sum_gran + e + 1, t1, tag);
-                        if (st->flags & PLAN_F_SUM_PLAIN) { st->sum_plain[e] = t0; st->sum_plain[e + 1] = t1; }
-                    }
-                }
-                *(float2 *) (c.stg + e) = make_float2(t0, t1);
-            }
-        }
+        if (two) { emit(ch, a0, a1, b0, b1); emit(c1, e0, e1, f0, f1); }
+        else     { emit(ch, a0, a1, 0.f, 0.f); emit(c1, b0, b1, 0.f, 0.f); emit(c2, e0, e1, 0.f, 0.f); emit(c3, f0, f1, 0.f, 0.f); }
     }
     return true;
 }
@@ -350,29 +391,43 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     // of being hoisted out of the stage loop for BOTH types' loaders, quantizers and pollers and kept live (and spilled)
     int lane = lane_id(); asm volatile("" : "+v"(lane));
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    PLAN_STAMP(0);
     const int k = st->k, flags = st->flags;
     int r_lo = (int) blockIdx.x * st->rows_per_wg, r_hi = r_lo + st->rows_per_wg;
     if (r_hi > st->total_rows) r_hi = st->total_rows;
+    StageW sw;
+    int pair_p0 = 0, pair_np = 0;
+    if (flags & PLAN_F_PAIRED) {                              // rows_per_wg = pairs per workgroup, total_rows = m: local rows [0, 2 np)
+        pair_p0 = r_lo; pair_np = max(0, r_hi - r_lo);
+        sw.load_paired(st, pair_p0, pair_np);
+        r_lo = 0; r_hi = 2 * pair_np;
+    } else sw.load(st);
     const StageGeom g = plan_geom<T>(k, r_hi);
 
     constexpr int PLAN_D = plan_depth(T);
     Chunk ring[PLAN_D];
     PlanCursor ld;
     ld.gr = r_lo + wave; ld.s = 0; ld.row = nullptr;
-    StageW sw; sw.load(st);
     if (ld.gr < r_hi) ld.row = sw.row_ptr(ld.gr);
-    PLAN_STAMP(0);
+#ifdef MI355Q_STAMPS
+    { unsigned long long probe = (unsigned long long) (uintptr_t) ld.row + (unsigned) k; asm volatile("" :: "s"(probe)); }   // (forces the descriptor's scalar loads to have returned)
+    PLAN_STAMP(5);
+#endif
     plan_fill<T, PLAN_D>(ring, 0, st->prime, ld, sw, g, lane);                 // weights start flowing before anything else
+    plan_prefetch_desc(c, wave, lane);
     PLAN_STAMP(1);
 
     if (flags & PLAN_F_NEW_X) {
         constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? FAM_Q80 : FAM_Q8K;
         plan_lds_barrier();                                   // all waves are done with the previous LDS image and staging area
+        const int x_kind = st->x_kind;
+        const float * nw = x_kind == MI355Q_X_NORM ? st->norm_w : nullptr;
+        float4 w_first = make_float4(1.f, 1.f, 1.f, 1.f);      // the norm weights of this wave's first span: fetched before the producers are polled
+        if (nw && wave * 256 + 4 * lane < k) w_first = *(const float4 *) (nw + wave * 256 + 4 * lane);
         double ssq;
         const bool ok = plan_gather(st, c, k, wave, lane, ssq);
         if (!ok && lane == 0) c.ctl[CTL_OK] = 0;
         PLAN_STAMP(2);
-        const int x_kind = st->x_kind;
         if (x_kind == MI355Q_X_NORM) {
             ssq = wave_sum_f64(ssq);
             if (lane == 0) c.part[wave] = ssq;
@@ -380,7 +435,6 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
         plan_lds_barrier();
         if (!c.ctl[CTL_OK]) return false;
         float scale = 1.0f;
-        const float * nw = nullptr;
         if (x_kind == MI355Q_X_NORM) {
             double s = 0.0;
 #pragma unroll
@@ -388,7 +442,6 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
             const float mean = (float) (s / (double) k);
             const float root = (float) sqrt((double) __fadd_rn(mean, st->eps));      // both roundings of the CPU (ops_glue.hip k_add_rms_norm_mul)
             scale = (float) (1.0 / (double) root);
-            nw = st->norm_w;
         }
         const int spans = (k + 255) >> 8;
 #pragma unroll 1
@@ -399,7 +452,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
                 v = *(const float4 *) (c.stg + e);
                 if (x_kind == MI355Q_X_NORM) {
                     v.x = __fmul_rn(v.x, scale); v.y = __fmul_rn(v.y, scale); v.z = __fmul_rn(v.z, scale); v.w = __fmul_rn(v.w, scale);
-                    if (nw) { const float4 ww = *(const float4 *) (nw + e); v.x = __fmul_rn(v.x, ww.x); v.y = __fmul_rn(v.y, ww.y); v.z = __fmul_rn(v.z, ww.z); v.w = __fmul_rn(v.w, ww.w); }
+                    if (nw) { const float4 ww = span == wave ? w_first : *(const float4 *) (nw + e); v.x = __fmul_rn(v.x, ww.x); v.y = __fmul_rn(v.y, ww.y); v.z = __fmul_rn(v.z, ww.z); v.w = __fmul_rn(v.w, ww.w); }
                 }
             }
             plan_quantize_span<FAM>(v, span, c.lds, k, c.even != 0, lane);
@@ -411,31 +464,39 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     PLAN_STAMP(3);
     ActView av[1];
     av[0].base = c.lds; av[0].k = k;
-    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av, c.epoch + st->tag_off, (flags & PLAN_F_PLAIN_Y) != 0);
+    float * pair_lds = (flags & PLAN_F_PAIRED) ? c.stg : nullptr;      // (the staging area is free once the activations are quantized)
+    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av, c.epoch + st->tag_off, (flags & PLAN_F_PLAIN_Y) != 0, pair_lds);
     PLAN_STAMP(4);
+    if (flags & PLAN_F_PAIRED) {
+        plan_lds_barrier();                                   // every wave's rows are in LDS
+        const int uop = st->x_unary >> 8;                     // (the output unary is kept in the high byte)
+        for (int i = (int) threadIdx.x; i < pair_np; i += GEMV_THREADS) {
+            const float t = __fmul_rn(unary_f(uop, pair_lds[i]), pair_lds[pair_np + i]);
+            publish(sw.g + pair_p0 + i, t, c.epoch + st->tag_off);
+            if (flags & PLAN_F_PLAIN_Y) sw.y0[pair_p0 + i] = t;
+        }
+    }
     return true;
 }
 
 // ---- attention of one token ------------------------------------------------------------------------------------------
 // Workgroup b = (head h, KV split sp).  LDS (inside the staging area): sq / sk / sv f32 [hd], kh / vh f16 [hd] (this token's
 // cache row, rounded as stored), sc f32 [per] (scores, then probabilities), red f32 [16][hd] (P V partials), maxs / sums [16].
-__device__ __forceinline__ float rope_theta(const AttnStage * a, int pos, int ip, float & mscale) {
-    const float ff = a->freq_factors ? a->freq_factors[ip] : 1.0f;
-    float th = (float) pos;
-    for (int j = 0; j < ip; ++j) th = __fmul_rn(th, a->theta_scale);          // repeated f32 multiplication, as ggml_rope_cache_init does
-    const float theta_extrap = __fdiv_rn(th, ff);
-    const float theta_interp = a->freq_scale * theta_extrap;
-    float theta = theta_interp; mscale = a->attn_factor;
-    if (a->ext_factor != 0.0f) {
-        const float y = ((float) ip - a->corr0) / fmaxf(0.001f, a->corr1 - a->corr0);
-        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * a->ext_factor;
-        theta = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
-        mscale *= 1.0f + 0.1f * logf(1.0f / a->freq_scale);
-    }
-    return theta;
-}
+typedef const __attribute__((address_space(4))) AttnStage * AttnC;          // the descriptor is read with scalar loads
 
-static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCtx & c, unsigned tag) {
+static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in, unsigned tag_in) {
+    const AttnC a = (AttnC) (uintptr_t) uniform_ptr((const void *) (uintptr_t) a_in);      // (see uniform_ptr)
+    // LDS pointers are re-derived from the kernel's LDS symbol: taken from the caller's struct they would be generic pointers (flat loads)
+    extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds_attn[];
+    StageCtx c;
+    c.image = __builtin_amdgcn_readfirstlane(c_in.image);
+    c.lds = plan_lds_attn; c.ctl = (int *) (plan_lds_attn + c.image); c.part = (double *) (plan_lds_attn + c.image + 64);
+    c.stg = (float *) (plan_lds_attn + c.image + 64 + 8 * GEMV_WAVES + 1024);
+    c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
+    c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
+    c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
+    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.pre_lds = c_in.pre_lds;
+    const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int tid = (int) threadIdx.x;
@@ -447,7 +508,21 @@ static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCt
     float * maxs = (float *) (vh + hd), * sums = maxs + GEMV_WAVES;
     float * red = sums + GEMV_WAVES;                                          // [16][hd]
     float * sc = red + GEMV_WAVES * hd;                                        // [per]
+    // loads that depend on nothing this launch computes are issued first: the token's position, its cache slots, the window, the mask
+    const int32_t * pos_p = a->pos, * nkv_p = a->n_kv_dev;
+    char * const * kdst_p = a->k_dst, * const * vdst_p = a->v_dst;
+    const int pos = pos_p[0];
+    char * const kdst = *kdst_p, * const vdst = *vdst_p;
+    int n_kv = a->n_kv;                                                        // the window of THIS run (the plan is sized for a->n_kv)
+    if (nkv_p) n_kv = min(n_kv, max(1, nkv_p[0]));
+    const int per = (n_kv + n_split - 1) / n_split;
+    const int j0 = sp * per, j1 = min(n_kv, j0 + per), cnt = max(0, j1 - j0);
+    const char * maskp = a->mask; const int mask_f16 = a->mask_f16;
     plan_lds_barrier();                                                        // the staging area is free (previous stage's quantizer is done)
+    plan_prefetch_desc(c, wave, lane);
+    PLAN_STAMP(0);
+    for (int jj = tid; jj < cnt; jj += GEMV_THREADS)                           // the additive mask of this split's positions (0 without a mask)
+        sc[jj] = maskp ? (mask_f16 ? __half2float(((const __half *) maskp)[j0 + jj]) : ((const float *) maskp)[j0 + jj]) : 0.0f;
 
     // 1. q head h, k / v head g  (hd <= 256: at most two 128-element chunks each)
     {
@@ -457,7 +532,11 @@ static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCt
         bool ok_all = true;
         for (int item = wave; item < 3 * nch; item += GEMV_WAVES) {
             const int which = item / nch, ch = item % nch;
-            const VecSrc & vs = which == 0 ? a->q : which == 1 ? a->k : a->v;
+            VecSrc vs;
+            if (which == 0)      { vs.plain = a->q.plain; vs.gran = a->q.gran; vs.tag_off = a->q.tag_off; }
+            else if (which == 1) { vs.plain = a->k.plain; vs.gran = a->k.gran; vs.tag_off = a->k.tag_off; }
+            else                 { vs.plain = a->v.plain; vs.gran = a->v.gran; vs.tag_off = a->v.tag_off; }
+            vs.pad = 0;
             const SrcView s = src_view(vs, (which == 0 ? h : g) * hd, hd, c.epoch);
             float * dst = which == 0 ? sq : which == 1 ? sk : sv;
             float v0, v1;
@@ -474,21 +553,34 @@ static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCt
     }
     plan_lds_barrier();
     if (!c.ctl[CTL_OK]) return false;
+    PLAN_STAMP(1);
 
     // 2. rope (ops_glue.hip k_rope / ggml-cpu/ops.cpp:5088-5270); q is then rounded to f16 as the CPU's f16 vec_dot does with src1,
     //    k and v to f16 as the cache stores them.  One rotated pair per thread: pairs of q first, then of k.
-    const int pos = a->pos[0];
     const int half = hd >> 1;
     if (tid < 2 * half) {
         float * x = tid < half ? sq : sk;
         const int ip = tid < half ? tid : tid - half;
         const int i0 = 2 * ip;
+        const int n_dims = a->n_dims, neox = a->neox;
         float r0, r1; int e0, e1;
-        if (i0 < a->n_dims) {
-            float mscale;
-            const float theta = rope_theta(a, pos, ip, mscale);
+        if (i0 < n_dims) {
+            const float * ffp = a->freq_factors;
+            const float ff = ffp ? ffp[ip] : 1.0f;
+            const float tscale = a->theta_scale;
+            float th = (float) pos;
+            for (int j = 0; j < ip; ++j) th = __fmul_rn(th, tscale);             // repeated f32 multiplication, as ggml_rope_cache_init does
+            const float theta_extrap = __fdiv_rn(th, ff);
+            const float theta_interp = a->freq_scale * theta_extrap;
+            float theta = theta_interp, mscale = a->attn_factor;
+            if (a->ext_factor != 0.0f) {
+                const float y = ((float) ip - a->corr0) / fmaxf(0.001f, a->corr1 - a->corr0);
+                const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * a->ext_factor;
+                theta = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+                mscale *= 1.0f + 0.1f * logf(1.0f / a->freq_scale);
+            }
             const float cs = cosf(theta) * mscale, sn = sinf(theta) * mscale;
-            e0 = a->neox ? ip : i0; e1 = a->neox ? ip + a->n_dims / 2 : i0 + 1;
+            e0 = neox ? ip : i0; e1 = neox ? ip + n_dims / 2 : i0 + 1;
             const float x0 = x[e0], x1 = x[e1];
             r0 = x0 * cs - x1 * sn; r1 = x0 * sn + x1 * cs;
         } else { e0 = i0; e1 = i0 + 1; r0 = x[e0]; r1 = x[e1]; }
@@ -500,52 +592,50 @@ static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCt
         vh[d] = __float2half_rn(sv[d]);
     }
     plan_lds_barrier();
-    char * const kdst = *a->k_dst, * const vdst = *a->v_dst;
     if (sp == 0 && h % gq == 0 && tid < hd) {                                   // this token's cache row: one workgroup per kv head stores it
         ((__half *) kdst)[g * hd + tid] = kh[tid];
         *(__half *) (vdst + (int64_t) (g * hd + tid) * a->v_dst_nb) = vh[tid];
     }
-    const int slot = (int) ((kdst - a->k_cache) / a->k_nb_pos);              // the position whose row is being stored right now: read from LDS
+    const char * kcache = a->k_cache;
+    const int64_t k_nb_pos = a->k_nb_pos;
+    const int slot = (int) ((kdst - kcache) / k_nb_pos);                       // the position whose row is being stored right now: read from LDS
+    PLAN_STAMP(2);
 
-    // 3. scores of this split's positions: one wave per position, a lane owns dims (2l, 2l+1) [+128]
-    int n_kv = a->n_kv;                                                        // the window of THIS run (the plan is sized for a->n_kv)
-    if (a->n_kv_dev) n_kv = min(n_kv, max(1, a->n_kv_dev[0]));
-    const int per = (n_kv + n_split - 1) / n_split;
-    const int j0 = sp * per, j1 = min(n_kv, j0 + per), cnt = max(0, j1 - j0);
-    const char * kbase = a->k_cache + (int64_t) g * a->k_nb_head;
+    // 3. scores of this split's positions: one wave per position (8 in flight), a lane owns dims (2l, 2l+1) [+128]
+    const char * kbase = kcache + (int64_t) g * a->k_nb_head;
+    const float scale = a->scale;
     const float q0 = 2 * lane < hd ? sq[2 * lane] : 0.f, q1 = 2 * lane < hd ? sq[2 * lane + 1] : 0.f;
     const float q2 = 2 * lane + 128 < hd ? sq[2 * lane + 128] : 0.f, q3 = 2 * lane + 128 < hd ? sq[2 * lane + 129] : 0.f;
+    constexpr int SB = 8;
 #pragma unroll 1
-    for (int jb = wave; jb < cnt; jb += 4 * GEMV_WAVES) {
-        __half2 kv[4], kw[4];
+    for (int jb = wave; jb < cnt; jb += SB * GEMV_WAVES) {
+        __half2 kv[SB], kw[SB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SB; ++u) {
             const int j = j0 + jb + u * GEMV_WAVES;
             kv[u] = __half2(); kw[u] = __half2();
             if (jb + u * GEMV_WAVES < cnt) {
                 if (j == slot) { if (2 * lane < hd) kv[u] = *(const __half2 *) (kh + 2 * lane); if (2 * lane + 128 < hd) kw[u] = *(const __half2 *) (kh + 2 * lane + 128); }
                 else {
-                    const char * row = kbase + (int64_t) j * a->k_nb_pos;
+                    const char * row = kbase + (int64_t) j * k_nb_pos;
                     if (2 * lane < hd) kv[u] = *(const __half2 *) (row + 4 * lane);
                     if (2 * lane + 128 < hd) kw[u] = *(const __half2 *) (row + 4 * lane + 256);
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SB; ++u) {
             if (jb + u * GEMV_WAVES < cnt) {
                 const float2 f = __half22float2(kv[u]), f2 = __half22float2(kw[u]);
                 float d = q0 * f.x + q1 * f.y + q2 * f2.x + q3 * f2.y;
                 d = wave_sum(d);
-                const int j = j0 + jb + u * GEMV_WAVES;
-                float m = 0.0f;
-                if (a->mask) m = a->mask_f16 ? __half2float(((const __half *) a->mask)[j]) : ((const float *) a->mask)[j];
                 // (a fully masked position stays -inf whatever its cache row holds: never-written rows may be anything, 0 * NaN included)
-                if (lane == 0) sc[jb + u * GEMV_WAVES] = m == -INFINITY ? -INFINITY : __fadd_rn(__fmul_rn(d, a->scale), m);
+                if (lane == 0) { const float m = sc[jb + u * GEMV_WAVES]; sc[jb + u * GEMV_WAVES] = m == -INFINITY ? -INFINITY : __fadd_rn(__fmul_rn(d, scale), m); }
             }
         }
     }
     plan_lds_barrier();
+    PLAN_STAMP(3);
     // 4. local softmax statistics
     float mx = -INFINITY;
     for (int j = tid; j < cnt; j += GEMV_THREADS) mx = fmaxf(mx, sc[j]);
@@ -555,40 +645,65 @@ static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCt
     mx = maxs[0];
 #pragma unroll
     for (int i = 1; i < GEMV_WAVES; ++i) mx = fmaxf(mx, maxs[i]);
-    float ls = 0.0f;
-    for (int j = tid; j < cnt; j += GEMV_THREADS) {
-        const float p = mx == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx));
-        sc[j] = p; ls += p;
-    }
-    ls = wave_sum(ls);
-    if (lane == 0) sums[wave] = ls;
-    plan_lds_barrier();
-    float l = 0.0f;
+    float l;
+    if (a->p_f16) {
+        // The non-flash graph of the reference (SOFT_MAX, then MUL_MAT(v, kq) whose f16 src0 makes the CPU round kq to f16): the whole window is in
+        // this workgroup, so the probabilities are formed exactly as ggml_compute_forward_soft_max_f32 does -- sum of the exponentials in f64,
+        // p = e * (float) (1 / sum) -- and rounded to f16 before they meet V.  (An f32 P.V is closer to the exact product, but the next matmul
+        // re-quantizes its input and amplifies any 1e-4 difference from the CPU to ~1 % of the logits: DESIGN.md section 3b.)
+        double ds = 0.0;
+        for (int j = tid; j < cnt; j += GEMV_THREADS) {
+            const float e = mx == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx));
+            sc[j] = e; ds += (double) e;
+        }
+        ds = wave_sum_f64(ds);
+        if (lane == 0) c.part[wave] = ds;
+        plan_lds_barrier();
+        double tot = 0.0;
 #pragma unroll
-    for (int i = 0; i < GEMV_WAVES; ++i) l += sums[i];
+        for (int i = 0; i < GEMV_WAVES; ++i) tot += c.part[i];
+        const float inv = (float) (1.0 / tot);
+        for (int j = tid; j < cnt; j += GEMV_THREADS) sc[j] = __half2float(__float2half_rn(__fmul_rn(sc[j], inv)));
+        plan_lds_barrier();
+        l = 1.0f;
+    } else {
+        float ls = 0.0f;
+        for (int j = tid; j < cnt; j += GEMV_THREADS) {
+            const float p = mx == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx));
+            sc[j] = p; ls += p;
+        }
+        ls = wave_sum(ls);
+        if (lane == 0) sums[wave] = ls;
+        plan_lds_barrier();
+        l = 0.0f;
+#pragma unroll
+        for (int i = 0; i < GEMV_WAVES; ++i) l += sums[i];
+    }
+    PLAN_STAMP(4);
     // 5. o[d] = sum_j p_j v[j][d]   (positions with p == 0 are skipped: masked cache rows may hold anything)
     const char * vbase = a->v_cache + (int64_t) g * a->v_nb_head;
-    if (a->v_nb_dim == 2) {
+    const int64_t v_nb_pos = a->v_nb_pos, v_nb_dim = a->v_nb_dim;
+    if (v_nb_dim == 2) {
         // rows per position (the -fa layout): a wave takes positions jb = wave, wave+16, ...; a lane owns dims (2l, 2l+1) [+128]
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 1
-        for (int jb = wave; jb < cnt; jb += 4 * GEMV_WAVES) {
-            __half2 vv[4], vw[4]; float p[4];
+        for (int jb = wave; jb < cnt; jb += SB * GEMV_WAVES) {
+            __half2 vv[SB], vw[SB]; float p[SB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SB; ++u) {
                 const int jj = jb + u * GEMV_WAVES, j = j0 + jj;
                 vv[u] = __half2(); vw[u] = __half2(); p[u] = jj < cnt ? sc[jj] : 0.0f;
                 if (p[u] != 0.0f) {
                     if (j == slot) { if (2 * lane < hd) vv[u] = *(const __half2 *) (vh + 2 * lane); if (2 * lane + 128 < hd) vw[u] = *(const __half2 *) (vh + 2 * lane + 128); }
                     else {
-                        const char * row = vbase + (int64_t) j * a->v_nb_pos;
+                        const char * row = vbase + (int64_t) j * v_nb_pos;
                         if (2 * lane < hd) vv[u] = *(const __half2 *) (row + 4 * lane);
                         if (2 * lane + 128 < hd) vw[u] = *(const __half2 *) (row + 4 * lane + 256);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SB; ++u) {
                 const float2 f = __half22float2(vv[u]), f2 = __half22float2(vw[u]);
                 o0 += p[u] * f.x; o1 += p[u] * f.y; o2 += p[u] * f2.x; o3 += p[u] * f2.y;
             }
@@ -603,34 +718,65 @@ static __device__ __noinline__ bool plan_attn(const AttnStage * a, const StageCt
             red[tid] = o;                                                      // (row 0 of red now holds o; every thread touches only its column)
         }
     } else {
-        // transposed cache (positions contiguous per dim): a wave takes dims d = wave, wave+16, ...; lanes run over the positions
+        // transposed cache (positions contiguous per dim): a wave takes dims d = wave + 16 i; lanes run over the positions; the loads of
+        // 8 dims are in flight together (one memory round trip per 64 positions instead of one per dim)
 #pragma unroll 1
-        for (int d = wave; d < hd; d += GEMV_WAVES) {
-            const char * col = vbase + (int64_t) d * a->v_nb_dim;
-            float o = 0.0f;
+        for (int d0 = wave; d0 < hd; d0 += SB * GEMV_WAVES) {
+            float o[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) o[u] = 0.0f;
+#pragma unroll 1
             for (int jj = lane; jj < cnt; jj += 64) {
                 const float p = sc[jj];
-                if (p != 0.0f) {
-                    const int j = j0 + jj;
-                    const float v = j == slot ? __half2float(vh[d]) : __half2float(*(const __half *) (col + (int64_t) j * a->v_nb_pos));
-                    o += p * v;
+                const int j = j0 + jj;
+                __half vv[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int d = d0 + u * GEMV_WAVES;
+                    vv[u] = __half();
+                    if (p != 0.0f && d < hd) vv[u] = j == slot ? vh[d] : *(const __half *) (vbase + (int64_t) d * v_nb_dim + (int64_t) j * v_nb_pos);
                 }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) o[u] += p * __half2float(vv[u]);
             }
-            o = wave_sum(o);
-            if (lane == 0) red[d] = o;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int d = d0 + u * GEMV_WAVES;
+                if (d < hd) { const float t = wave_sum(o[u]); if (lane == 0) red[d] = t; }     // (d wave-uniform)
+            }
         }
     }
     plan_lds_barrier();
-    // 6. publish (o, m, l) of this split
-    Granule * part = a->part + (size_t) ((size_t) h * n_split + sp) * (hd + 2);
-    if (tid < hd) publish(part + tid, red[tid], tag);
-    else if (tid == hd) publish(part + hd, mx, tag);
-    else if (tid == hd + 1) publish(part + hd + 1, l, tag);
+    // 6. publish: the normalized output when the head is not split, else (o, m, l) of this split for the merge stage
+    if (n_split == 1) {
+        if (tid < hd) {
+            const float r = a->p_f16 ? red[tid] : __fdiv_rn(red[tid], l);
+            publish(a->out_gran + h * hd + tid, r, tag);
+            if (a->plain) a->out_plain[h * hd + tid] = r;
+        }
+    } else {
+        Granule * part = a->part + (size_t) ((size_t) h * n_split + sp) * (hd + 2);
+        if (tid < hd) publish(part + tid, red[tid], tag);
+        else if (tid == hd) publish(part + hd, mx, tag);
+        else if (tid == hd + 1) publish(part + hd + 1, l, tag);
+    }
+    PLAN_STAMP(5);
     return true;
 }
 
 // merge the KV splits of a head: out = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s     (workgroup h * n_split does head h)
-static __device__ __noinline__ bool plan_attn_combine(const AttnStage * a, const StageCtx & c, unsigned tag) {
+static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const StageCtx & c_in, unsigned tag_in) {
+    const AttnC a = (AttnC) (uintptr_t) uniform_ptr((const void *) (uintptr_t) a_in);
+    const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
+    extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds_comb[];
+    StageCtx c;
+    c.image = __builtin_amdgcn_readfirstlane(c_in.image);
+    c.lds = plan_lds_comb; c.ctl = (int *) (plan_lds_comb + c.image); c.part = (double *) (plan_lds_comb + c.image + 64);
+    c.stg = (float *) (plan_lds_comb + c.image + 64 + 8 * GEMV_WAVES + 1024);
+    c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
+    c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
+    c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
+    c.next_desc = nullptr; c.next_attn = nullptr; c.pre_lds = c_in.pre_lds;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int tid = (int) threadIdx.x;
@@ -640,6 +786,7 @@ static __device__ __noinline__ bool plan_attn_combine(const AttnStage * a, const
     const int n = n_split * (hd + 2);
     float * buf = c.stg;
     plan_lds_barrier();
+    PLAN_STAMP(0);
     {
         VecSrc vs; vs.plain = nullptr; vs.gran = a->part + (size_t) h * n; vs.tag_off = 0; vs.pad = 0;
         SrcView s = src_view(vs, 0, n, 0); s.expect = tag - 1;                  // the partials carry the ATTN stage's tag (the stage before this one)
@@ -675,6 +822,7 @@ static __device__ __noinline__ bool plan_attn_combine(const AttnStage * a, const
         publish(a->out_gran + h * hd + tid, r, tag);
         if (a->plain) a->out_plain[h * hd + tid] = r;
     }
+    PLAN_STAMP(2);
     return true;
 }
 
@@ -687,8 +835,9 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
 
     StageCtx c;
     c.lds = lds; c.ctl = (int *) (lds + lds_image_bytes); c.part = (double *) (lds + lds_image_bytes + 64);
-    c.stg = (float *) (lds + lds_image_bytes + 64 + 8 * GEMV_WAVES);
-    c.sync = sync; c.timeout = timeout_ticks; c.grid = gridDim.x; c.even = even; c.epoch = epoch;
+    c.stg = (float *) (lds + lds_image_bytes + 64 + 8 * GEMV_WAVES + 1024);
+    c.pre_lds = (unsigned) (size_t) (lds + lds_image_bytes + 64 + 8 * GEMV_WAVES);
+    c.sync = sync; c.timeout = timeout_ticks; c.grid = gridDim.x; c.even = even; c.epoch = epoch; c.image = lds_image_bytes;
     if (threadIdx.x == 0) c.ctl[CTL_OK] = 1;
     plan_lds_barrier();
 
@@ -696,6 +845,8 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
     for (int s = 0; s < n_stages; ++s) {
         StageC st = stages + s;
         c.stage = s;
+        c.next_desc = s + 1 < n_stages ? (const uint8_t *) (stages_g + s + 1) : nullptr;
+        c.next_attn = (const uint8_t *) st->next_attn;
         bool ok = true;
         const int kind = st->kind;
         if (kind == PLAN_K_GEMV) {
@@ -708,9 +859,9 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
             default: break;
             }
         } else if (kind == PLAN_K_ATTN) {
-            ok = plan_attn(st->attn, c, epoch + st->tag_off);
+            ok = plan_attn((AttnC) st->attn, c, epoch + st->tag_off);
         } else {
-            ok = plan_attn_combine(st->attn, c, epoch + st->tag_off);
+            ok = plan_attn_combine((AttnC) st->attn, c, epoch + st->tag_off);
         }
         if (!ok) return;
     }
@@ -757,7 +908,7 @@ extern "C" {
 void mi355q_set_error(const char * msg);          // api.hip
 
 // outputs published so far while the stage list is built: [ptr, ptr + n) f32 <-> granule offset, producing stage
-namespace { struct OutRange { const float * p; int64_t n; size_t gran_off; unsigned tag_off; }; }
+namespace { struct OutRange { const float * p; int64_t n; size_t gran_off; unsigned tag_off; int64_t id; }; }
 
 int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_stages, int flags) {
     if (!out || !stages || n_stages < 1) { mi355q_set_error("plan_create: null argument / no stages"); return MI355Q_ERR_SHAPE; }
@@ -770,22 +921,30 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
     std::vector<int> attn_of;                                  // per internal stage: index into va or -1
     std::vector<OutRange> outs;
     size_t gran_count = 0;
-    auto new_out = [&](const float * p, int64_t n, unsigned tag_off) {
-        OutRange r = { p, n, gran_count, tag_off };
+    auto new_out = [&](const float * p, int64_t n, unsigned tag_off, int64_t id) {
+        OutRange r = { p, n, gran_count, tag_off, id };
         gran_count += (size_t) ((n + 1) & ~(int64_t) 1);       // keep every vector 16-byte aligned
         outs.push_back(r);
         return r.gran_off;
     };
     // operand -> plain or the granules of the LATEST earlier output that contains it
-    auto resolve = [&](const float * p, int64_t n, VecSrc & vs) -> bool {
+    auto resolve = [&](const float * p, int64_t n, int64_t id, VecSrc & vs) -> bool {
         vs.plain = p; vs.gran = nullptr; vs.tag_off = 0; vs.pad = 0;
         if (!p) return true;
+        auto take = [&](const OutRange & r) { vs.gran = (const Granule *) (uintptr_t) (r.gran_off + (size_t) (p - r.p) + 1); vs.tag_off = r.tag_off; vs.plain = nullptr; };   // (offset + 1: patched to a pointer below)
+        if (id != 0) {                                         // labelled operand: the latest output with this id; the addresses give the offset inside it
+            for (size_t i = outs.size(); i-- > 0;) if (outs[i].id == id) { if (p < outs[i].p || p + n > outs[i].p + outs[i].n) return false; take(outs[i]); return true; }
+            return false;                                      // no stage produces this value
+        }
+        // By address: the LATEST earlier output that CONTAINS the operand produced it.  Later outputs that merely overlap it are other tensors to
+        // which the caller's allocator has handed the (by then dead) memory: inside the plan every value lives in its own granules, so they do not matter.
+        bool overlapped = false;
         for (size_t i = outs.size(); i-- > 0;) {
             const OutRange & r = outs[i];
-            if (p >= r.p && p + n <= r.p + r.n) { vs.gran = (const Granule *) (uintptr_t) (r.gran_off + (size_t) (p - r.p) + 1); vs.tag_off = r.tag_off; vs.plain = nullptr; return true; }   // (offset + 1: patched to a pointer below)
-            if (p < r.p + r.n && r.p < p + n) return false;    // straddles an output: not expressible
+            if (p >= r.p && p + n <= r.p + r.n) { take(r); return true; }
+            if (p < r.p + r.n && r.p < p + n) overlapped = true;
         }
-        return true;
+        return !overlapped;                                    // a plain operand whose memory a stage of this plan overwrites: not expressible
     };
     unsigned set = 0; size_t lds_max = 0, stg_max = 0; int64_t bytes = 0;
     for (int s = 0; s < n_stages; ++s) {
@@ -800,13 +959,17 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             if (at->n_head > n_cu) { mi355q_set_error("plan_create: attn stage: more heads than CUs"); return MI355Q_ERR_UNSUPPORTED; }
             AttnStage A = {};
             const int hd = at->head_dim;
-            if (!resolve(at->q, (int64_t) at->n_head * hd, A.q) || !resolve(at->k, (int64_t) at->n_head_kv * hd, A.k) || !resolve(at->v, (int64_t) at->n_head_kv * hd, A.v)) { mi355q_set_error("plan_create: attn operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
+            if (!resolve(at->q, (int64_t) at->n_head * hd, at->q_id, A.q) || !resolve(at->k, (int64_t) at->n_head_kv * hd, at->k_id, A.k) || !resolve(at->v, (int64_t) at->n_head_kv * hd, at->v_id, A.v)) { mi355q_set_error("plan_create: attn operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
             A.pos = at->pos; A.n_kv_dev = at->n_kv_dev; A.freq_factors = at->freq_factors; A.k_cache = (const char *) at->k_cache; A.v_cache = (const char *) at->v_cache;
             A.k_nb_pos = at->k_nb_pos; A.k_nb_head = at->k_nb_head; A.v_nb_pos = at->v_nb_pos; A.v_nb_dim = at->v_nb_dim; A.v_nb_head = at->v_nb_head; A.v_dst_nb = at->v_dst_nb;
             A.k_dst = (char * const *) at->k_dst; A.v_dst = (char * const *) at->v_dst; A.mask = (const char *) at->mask; A.mask_f16 = at->mask_f16;
             A.n_head = at->n_head; A.n_head_kv = at->n_head_kv; A.hd = hd; A.n_kv = at->n_kv; A.scale = at->scale;
-            A.n_split = n_cu / at->n_head; if (A.n_split < 1) A.n_split = 1; if (A.n_split > at->n_kv) A.n_split = at->n_kv;
+            // KV splits per head: one workgroup per 256 positions, at most #CU / n_head.  A window of <= 256 positions is ONE workgroup per head and
+            // needs no merge stage (a dependent hop costs more than reading 256 cache rows).
+            A.n_split = (at->n_kv + 255) / 256; if (A.n_split > n_cu / at->n_head) A.n_split = n_cu / at->n_head; if (A.n_split < 1) A.n_split = 1;
+            if (const char * e = getenv("MI355Q_PLAN_KV_SPLIT")) { const int sp = atoi(e); if (sp >= 1 && sp <= n_cu / at->n_head) A.n_split = sp; }
             A.per = (at->n_kv + A.n_split - 1) / A.n_split;
+            A.p_f16 = A.n_split == 1 && at->v_nb_pos == 2;     // the non-flash graph with the window in one workgroup: the CPU's f16-rounded probabilities
             A.plain = (in.flags & MI355Q_STAGE_NO_PLAIN) ? 0 : 1; A.out_plain = at->out;
             A.n_dims = at->rope.n_dims; A.neox = at->rope.mode == 2; A.freq_scale = at->rope.freq_scale; A.ext_factor = at->rope.ext_factor; A.attn_factor = at->rope.attn_factor;
             A.theta_scale = powf(at->rope.freq_base, -2.0f / at->rope.n_dims);
@@ -815,14 +978,19 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 const float start = floorf(corr_dim(at->rope.beta_fast)), end = ceilf(corr_dim(at->rope.beta_slow));
                 A.corr0 = start > 0 ? start : 0; A.corr1 = end < at->rope.n_dims - 1 ? end : (float) (at->rope.n_dims - 1);
             }
-            // the two internal stages: partial attention per (head, split), then the merge
+            // internal stages: attention per (head, split) and, when the heads are split, the merge
             PlanStage p = {}; p.kind = PLAN_K_ATTN; p.tag_off = (unsigned) v.size() + 1; p.flags = PLAN_F_NEW_X;
-            const size_t part_off = gran_count; gran_count += (size_t) at->n_head * A.n_split * (hd + 2); gran_count = (gran_count + 1) & ~(size_t) 1;
-            A.part = (Granule *) (uintptr_t) (part_off + 1);
-            v.push_back(p); attn_of.push_back((int) va.size());
-            PlanStage q = {}; q.kind = PLAN_K_COMBINE; q.tag_off = (unsigned) v.size() + 1; q.flags = PLAN_F_NEW_X;
-            A.out_gran = (Granule *) (uintptr_t) (new_out(at->out, (int64_t) at->n_head * hd, q.tag_off) + 1);
-            v.push_back(q); attn_of.push_back((int) va.size());
+            if (A.n_split == 1) {
+                A.out_gran = (Granule *) (uintptr_t) (new_out(at->out, (int64_t) at->n_head * hd, p.tag_off, at->out_id) + 1);
+                v.push_back(p); attn_of.push_back((int) va.size());
+            } else {
+                const size_t part_off = gran_count; gran_count += (size_t) at->n_head * A.n_split * (hd + 2); gran_count = (gran_count + 1) & ~(size_t) 1;
+                A.part = (Granule *) (uintptr_t) (part_off + 1);
+                v.push_back(p); attn_of.push_back((int) va.size());
+                PlanStage q = {}; q.kind = PLAN_K_COMBINE; q.tag_off = (unsigned) v.size() + 1; q.flags = PLAN_F_NEW_X;
+                A.out_gran = (Granule *) (uintptr_t) (new_out(at->out, (int64_t) at->n_head * hd, q.tag_off, at->out_id) + 1);
+                v.push_back(q); attn_of.push_back((int) va.size());
+            }
             va.push_back(A);
             const size_t need = (size_t) 4 * (3 * hd + hd /* kh, vh */ + 2 * GEMV_WAVES + GEMV_WAVES * hd + A.per) + 64;
             const size_t need2 = (size_t) 4 * A.n_split * (hd + 2) + 64;
@@ -838,8 +1006,12 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
         if (in.x_kind == MI355Q_X_PLAIN && in.x1) { mi355q_set_error("plan_create: X_PLAIN takes one operand"); return MI355Q_ERR_SHAPE; }
         if (in.x_kind == MI355Q_X_NORM && (((uintptr_t) in.norm_w & 15) || (in.k & 3))) { mi355q_set_error("plan_create: norm weights must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
         if (in.x1 && ((uintptr_t) in.x1 & 7)) { mi355q_set_error("plan_create: x1 must be 8-byte aligned"); return MI355Q_ERR_ALIGN; }
+        const bool paired = in.y_kind == MI355Q_Y_UNARY_MUL;
+        if (paired && (in.n_mats != 2 || in.mats[0].type != in.mats[1].type || in.mats[0].m != in.mats[1].m ||
+                       (in.y_unary != MI355Q_UNARY_SILU && in.y_unary != MI355Q_UNARY_RELU && in.y_unary != MI355Q_UNARY_SIGMOID))) { mi355q_set_error("plan_create: Y_UNARY_MUL needs two matrices of one type and size and SILU / RELU / SIGMOID"); return MI355Q_ERR_UNSUPPORTED; }
+        if (in.y_kind != MI355Q_Y_ROWS && !paired) { mi355q_set_error("plan_create: unknown y_kind"); return MI355Q_ERR_UNSUPPORTED; }
         VecSrc x0, x1;
-        if (!resolve(in.x, in.k, x0) || !resolve(in.x1, in.k, x1)) { mi355q_set_error("plan_create: an activation operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
+        if (!resolve(in.x, in.k, in.x_id, x0) || !resolve(in.x1, in.k, in.x1_id, x1)) { mi355q_set_error("plan_create: an activation operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
         bool done[GEMV_MAX_MATS] = { false, false, false, false };
         bool first = true;
         for (int i = 0; i < in.n_mats; ++i) {
@@ -860,8 +1032,8 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 if (((uintptr_t) m.w | (uintptr_t) m.w_stride) & 15) { mi355q_set_error("plan_create: planar rows must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
                 if (m.w_stride < mi355q_row_size(type, in.k)) { mi355q_set_error("plan_create: w_stride smaller than a row"); return MI355Q_ERR_SHAPE; }
                 p.w[n] = (const uint8_t *) m.w; p.y[n] = m.y; p.w_stride[n] = m.w_stride; p.row_begin[n] = (int) rows;
-                {   // the stage's granules form one block indexed by concatenated row: matrix n starts at gran_count + rows
-                    OutRange r = { m.y, m.m, sub_base + (size_t) rows, p.tag_off };
+                if (!paired || n == 0) {   // the stage's granules form one block indexed by concatenated row: matrix n starts at gran_count + rows
+                    OutRange r = { m.y, m.m, sub_base + (size_t) rows, p.tag_off, in.y_id[j] };
                     outs.push_back(r);
                 }
                 rows += m.m; bytes += m.m * mi355q_row_size(type, in.k); ++n;
@@ -877,10 +1049,12 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             if (first && in.x_kind == MI355Q_X_NORM && in.x1 && in.sum_out) {
                 p.flags |= PLAN_F_SUM | ((in.flags & MI355Q_STAGE_NO_PLAIN) ? 0 : PLAN_F_SUM_PLAIN);
                 p.sum_plain = in.sum_out;
-                p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off) + 1);
+                p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off, in.sum_id) + 1);
             }
+            if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;
+            if (paired && (size_t) (2 * rpw * 4 + 64) > stg_max) stg_max = (size_t) (2 * rpw * 4 + 64);
             p.prime = plan_depth(type);
             v.push_back(p); attn_of.push_back(-1);
             set |= tbit(type);
@@ -891,7 +1065,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
         }
     }
     if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
-    const size_t lds_total = lds_max + 64 + 8 * GEMV_WAVES + ((stg_max + 15) & ~(size_t) 15);
+    const size_t lds_total = lds_max + 64 + 8 * GEMV_WAVES + 1024 + ((stg_max + 15) & ~(size_t) 15);
     if (lds_total > 160 * 1024 - 64) { mi355q_set_error("plan_create: k / attention window too large for the LDS staging area"); return MI355Q_ERR_UNSUPPORTED; }
     if (const char * e = getenv("MI355Q_PLAN_PRIME")) { const int pr = atoi(e); for (auto & p : v) if (p.kind == PLAN_K_GEMV && pr >= 0 && pr < p.prime) p.prime = pr; }
 
@@ -920,6 +1094,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             fixs(p.x0); fixs(p.x1); p.sum_gran = (Granule *) fix(p.sum_gran);
             p.yg = (Granule *) fix(p.yg);
             p.attn = attn_of[i] >= 0 ? pl->d_attn + attn_of[i] : nullptr;
+            p.next_attn = i + 1 < v.size() && attn_of[i + 1] >= 0 ? pl->d_attn + attn_of[i + 1] : nullptr;
         }
         ok = hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) == hipSuccess &&
              (va.empty() || hipMemcpy(pl->d_attn, va.data(), va.size() * sizeof(AttnStage), hipMemcpyHostToDevice) == hipSuccess) &&

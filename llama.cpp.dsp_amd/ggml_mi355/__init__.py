@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_status_async", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
     "mi355q_plan_destroy",
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
-    "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale", "mi355q_op_cpy_indirect",
+    "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale", "mi355q_op_cpy_indirect", "mi355q_op_argsort", "mi355q_op_sum_rows",
     "mi355q_graph_capture_begin", "mi355q_graph_capture_end", "mi355q_graph_launch", "mi355q_graph_destroy",
     "mi355q_op_add_rms_norm_mul", "mi355q_op_unary_mul", "mi355q_op_flash_attn_ext", "mi355q_op_flash_attn_ext_workspace",
 ]
@@ -82,18 +82,20 @@ class _Attn(C.Structure):          # mi355q_attn
                 ("k_nb_pos", C.c_int64), ("k_nb_head", C.c_int64), ("v_nb_pos", C.c_int64), ("v_nb_dim", C.c_int64), ("v_nb_head", C.c_int64),
                 ("k_dst", C.c_void_p), ("v_dst", C.c_void_p), ("v_dst_nb", C.c_int64), ("mask", C.c_void_p), ("mask_f16", C.c_int),
                 ("n_head", C.c_int), ("n_head_kv", C.c_int), ("head_dim", C.c_int), ("n_kv", C.c_int), ("scale", C.c_float), ("out", C.c_void_p),
-                ("n_kv_dev", C.c_void_p)]
+                ("n_kv_dev", C.c_void_p), ("q_id", C.c_int64), ("k_id", C.c_int64), ("v_id", C.c_int64), ("out_id", C.c_int64)]
 
 
 class _Stage(C.Structure):         # mi355q_stage
     _fields_ = [("mats", _Mat * 4), ("n_mats", C.c_int), ("flags", C.c_int), ("x", C.c_void_p), ("k", C.c_int64),
                 ("kind", C.c_int), ("x_kind", C.c_int), ("x_unary", C.c_int), ("eps", C.c_float),
-                ("x1", C.c_void_p), ("norm_w", C.c_void_p), ("sum_out", C.c_void_p), ("attn", C.POINTER(_Attn))]
+                ("x1", C.c_void_p), ("norm_w", C.c_void_p), ("sum_out", C.c_void_p), ("attn", C.POINTER(_Attn)),
+                ("y_id", C.c_int64 * 4), ("sum_id", C.c_int64), ("x_id", C.c_int64), ("x1_id", C.c_int64), ("y_kind", C.c_int), ("y_unary", C.c_int)]
 
 
 STAGE_DEPENDS, STAGE_NO_PLAIN = 0x1, 0x2
 STAGE_GEMV, STAGE_ATTN = 0, 1
 X_PLAIN, X_NORM, X_UNARY_MUL = 0, 1, 2
+Y_ROWS, Y_UNARY_MUL = 0, 1
 
 
 class _Tensor(C.Structure):
@@ -152,7 +154,9 @@ def lib() -> C.CDLL:
     L.mi355q_op_mul_mat_f.argtypes = [TP, TP, TP, vp]
     L.mi355q_op_get_rows.argtypes = [TP, TP, TP, vp]
     L.mi355q_op_scale.argtypes = [TP, TP, C.c_float, vp]
-    L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64]
+    L.mi355q_op_argsort.argtypes = [TP, TP, i32, vp]
+    L.mi355q_op_sum_rows.argtypes = [TP, TP, vp]
+    L.mi355q_mul_mat_id_workspace.restype = sz; L.mi355q_mul_mat_id_workspace.argtypes = [i32, i64, i64, i64, i64, i64, i64]
     L.mi355q_mul_mat_id.argtypes = [i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, i64, i64, i64, vp, sz, i32, vp]
     _lib = L
     return L
@@ -301,7 +305,8 @@ class Plan:
     stages: a list whose entries are
       * (weights: list[QWeight] (<= 4, same K), x: f32 [1, K] or [K], ys: list of f32 [1, M_i] / [M_i], depends)   -- a plain GEMV stage
         (`depends` is accepted for API version 1 and ignored: an x that is an earlier stage's output is found by its address), or
-      * dict(ws=, ys=, x=, x_kind=X_PLAIN|X_NORM|X_UNARY_MUL, x1=None, norm_w=None, eps=0.0, sum_out=None, unary=UNARY_SILU, no_plain=False), or
+      * dict(ws=, ys=, x=, x_kind=X_PLAIN|X_NORM|X_UNARY_MUL, x1=None, norm_w=None, eps=0.0, sum_out=None, unary=UNARY_SILU, no_plain=False,
+             y_kind=Y_ROWS|Y_UNARY_MUL (two weights: ys[0] = y_unary(W0 x) * (W1 x), ys[1] unused), y_unary=UNARY_SILU), or
       * dict(attn=dict(q=, k=, v=, pos=, rope=dict(n_dims=, mode=0, n_ctx_orig=0, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0,
                        attn_factor=1.0, beta_fast=32.0, beta_slow=1.0), freq_factors=None, k_cache=, v_cache=, k_nb_pos=, k_nb_head=, v_nb_pos=,
                        v_nb_dim=, v_nb_head=, k_dst=, v_dst= (int64 device tensors holding the destination ADDRESSES), v_dst_nb=, mask=None,
@@ -335,6 +340,7 @@ class Plan:
                     st.x_kind = sd.get("x_kind", X_PLAIN); st.x_unary = sd.get("unary", UNARY_SILU); st.eps = float(sd.get("eps", 0.0))
                     st.x1 = ptr(sd.get("x1")); st.norm_w = ptr(sd.get("norm_w")); st.sum_out = ptr(sd.get("sum_out"))
                     st.flags = STAGE_NO_PLAIN if sd.get("no_plain") else 0
+                    st.y_kind = sd.get("y_kind", Y_ROWS); st.y_unary = sd.get("y_unary", UNARY_SILU)
                     for t in (sd.get("x1"), sd.get("norm_w"), sd.get("sum_out")):
                         assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x.shape[-1])
                 else:
@@ -490,6 +496,23 @@ def op_get_rows(a, ids, out=None):
     return out
 
 
+def op_argsort(a, descending: bool = False):
+    """GGML_OP_ARGSORT per row of the last dimension: int32 indices, rank order (ties keep index order)."""
+    torch = _torch()
+    out = torch.empty(a.shape, dtype=torch.int32, device=a.device)
+    d = _td(out.view(torch.float32)); d.type = 0
+    _check(lib().mi355q_op_argsort(C.byref(_td(a)), C.byref(d), 1 if descending else 0, _stream(torch)), "op_argsort")
+    return out
+
+
+def op_sum_rows(a):
+    """GGML_OP_SUM_ROWS: sums over the last (ggml: first) dimension, keeping it with size 1."""
+    torch = _torch()
+    out = torch.empty(tuple(a.shape[:-1]) + (1,), dtype=torch.float32, device=a.device)
+    _check(lib().mi355q_op_sum_rows(C.byref(_td(a)), C.byref(_td(out)), _stream(torch)), "op_sum_rows")
+    return out
+
+
 def op_scale(a, scale: float, out=None):
     torch = _torch()
     out = out if out is not None else torch.empty_like(a, memory_format=torch.contiguous_format)
@@ -515,7 +538,7 @@ def mul_mat_id(w: QWeight, x, ids, flags: int = 0):
     n_tok, x_ne1, _ = x.shape
     n_used = ids.shape[1]
     y = torch.empty((n_tok, n_used, w.M), dtype=torch.float32, device=x.device)
-    ws, wsb = _workspace(torch, int(lib().mi355q_mul_mat_id_workspace(w.type, w.M, w.K, n_used, n_tok, x_ne1)), x.device)
+    ws, wsb = _workspace(torch, int(lib().mi355q_mul_mat_id_workspace(w.type, w.M, w.K, n_used, n_tok, x_ne1, w.n_expert)), x.device)
     _check(lib().mi355q_mul_mat_id(w.type, w.data.data_ptr(), w.row_bytes, w.row_bytes * w.M, w.n_expert,
                                    x.data_ptr(), x_ne1, x.stride(1) * 4, x.stride(0) * 4,
                                    ids.data_ptr(), ids.stride(0) * 4, y.data_ptr(), w.M, w.K, n_used, n_tok,

@@ -206,3 +206,21 @@ def test_flash_attn_ext(G, torch, cfg):
     err = np.abs(y - ref).max()
     # (prefill batches round the probabilities to f16 for the matrix cores: 2^-11 relative on each of them)
     assert err <= (2e-5 if N < 16 or softcap else 4e-4) * max(1.0, np.abs(ref).max()), (cfg, err)
+
+
+def test_argsort_and_sum_rows(G, torch):
+    """The MoE router ops (GGML_OP_ARGSORT as ggml_top_k uses it, GGML_OP_SUM_ROWS): against numpy (stable order on ties; f64 row sums)."""
+    rng = np.random.default_rng(12)
+    for shape in ((1, 1, 5, 8), (1, 2, 33, 256), (2, 3, 7, 60), (1, 1, 3, 1000)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[..., 3] = x[..., 1]                                           # ties
+        for desc in (False, True):
+            got = G.op_argsort(dev(torch, x), descending=desc).cpu().numpy()
+            want = np.argsort(-x if desc else x, axis=-1, kind="stable").astype(np.int32)
+            assert np.array_equal(got, want), (shape, desc)
+        s = G.op_sum_rows(dev(torch, x)).cpu().numpy()
+        assert np.array_equal(bits(s), bits(x.astype(np.float64).sum(-1, keepdims=True).astype(np.float32))), shape
+    # a strided source (the router reads a view of the probabilities)
+    x = rng.standard_normal((4, 64)).astype(np.float32)
+    xs = dev(torch, x)[:, ::2]
+    assert np.array_equal(G.op_sum_rows(xs).cpu().numpy().reshape(-1), x[:, ::2].astype(np.float64).sum(-1).astype(np.float32))

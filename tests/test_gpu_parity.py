@@ -581,3 +581,27 @@ def test_plan_llama70b_layer_against_oracle(G, torch, orc):
             rows = np.unique(np.concatenate([[0, w.M - 1], rng.integers(0, w.M, 48)]))
             check_close(y.cpu().numpy()[:, rows], orc.mul_mat(w.type, h[rows], x.cpu().numpy(), len(rows), 1, w.K), f"70B layer {ids_t(w.type)} {w.M}x{w.K}")
     plan.close()
+
+
+@pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.IQ4_XS], ids=ids_t)
+@pytest.mark.parametrize("n_tok", [2, 64])
+def test_mul_mat_id_out_of_range_expert_is_nan_on_every_path(G, torch, orc, t, n_tok):
+    """One rule for an expert id outside [0, n_expert) -- on which the reference asserts -- on all device paths (per-pair GEMV with the ids read
+    on the device, the device-grouped matrix-core form, the generic tier): that pair's output row is NaN, every other row is unaffected."""
+    rng = np.random.default_rng(3 + t + n_tok)
+    ne, nu, M, K = 4, 2, 64, 2048
+    as_ = quantized_weights(t, ne * M, K, rng)
+    w = G.QWeight.from_host(t, as_, M, K, n_expert=ne)
+    ids = np.stack([rng.permutation(ne)[:nu] for _ in range(n_tok)]).astype(np.int32)
+    good = ids.copy()
+    ids[0, 1] = ne; ids[n_tok - 1, 0] = -1
+    b = rng.uniform(-1, 1, (n_tok, 1, K)).astype(np.float32)
+    y = G.mul_mat_id(w, torch.from_numpy(b).cuda(), torch.from_numpy(ids).cuda()).cpu().numpy()
+    assert np.isnan(y[0, 1]).all() and np.isnan(y[n_tok - 1, 0]).all()
+    ref = orc.mul_mat_id(t, as_, b, good, M, K, ne)
+    ok = np.ones((n_tok, nu), bool); ok[0, 1] = False; ok[n_tok - 1, 0] = False
+    assert np.isfinite(y[ok]).all()
+    if n_tok * nu >= 17 and t == oracle.Q6_K:
+        assert nmse(y[ok], ref[ok]) <= 5e-4
+    else:
+        check_close(y[ok], ref[ok])
