@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--no-fuse", action="store_true", help="one launch per matrix (no q/k/v, gate/up fusion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plugin", action="store_true", help="skip the whole-model leg through ggml_backend_graph_compute of the plugin")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="plumbing only (CPU/gloo test of the N>1 hop protocol): no GPU work")
     return ap.parse_args()
@@ -301,6 +302,39 @@ def cpu_baseline(specs, seconds):
                       f"{iters} evaluations, oracle/_ref/{variant} (ggml CPU backend built from the reference sources)"}
 
 
+def plugin_graph_compute(seconds_cap=240):
+    """The same decode step one level further out: a whole Llama-3-8B-shaped model (32 layers, 128256-row output matrix, random Q4_K_M weights)
+    built with the reference's own ggml graph API and run token by token through ggml_backend_graph_compute of libggml-mi355.so, timed per token
+    with everything llama_decode does around it (graph build, allocation, input upload, compute, synchronize) -- and the reference's CPU backend
+    on the same graphs beside it.  The host side is the reference's libggml (oracle/_ref, compiled from /root/reference; it cannot be shipped in
+    this repo) driven by oracle/model_parity/model_parity.cc, so this leg belongs to the CPU-baseline half of the report: a measurement of the
+    product through the reference's plugin API, never a dependency of the product."""
+    import re, subprocess
+    import oracle
+    variant = oracle.best_ref_variant()
+    exe = ROOT / "oracle" / "_ref" / (variant or "avx2") / "model_parity"
+    plugin = ROOT / "llama.cpp.dsp_amd" / "lib" / "libggml-mi355.so"
+    if variant is None or not exe.exists() or not plugin.exists():
+        return None
+    env = dict(os.environ, GGML_BACKEND_PATH=str(plugin), MI355_GRAPH_STATS="1")
+    r = subprocess.run([str(exe), "--preset", "8b", "--layers", "32", "--vocab", "128256", "--tokens", "2", "--bench", "128"], env=env, capture_output=True, text=True, timeout=seconds_cap)
+    m = re.search(r"decode through (\S+) \((.*?)\): \S+ ([0-9.]+) us/token = ([0-9.]+) tok/s(?:; CPU backend ([0-9.]+) us/token = ([0-9.]+) tok/s \((\d+) tokens\))?", r.stdout)
+    if not m:
+        return {"error": f"model_parity exit {r.returncode}", "tail": (r.stdout + r.stderr)[-400:]}
+    # (exit code 1 only says that the live comparison exceeded the single-op bound of 1e-3: whole-model logits of two correct evaluations differ
+    # by more -- DESIGN.md section 3b; tests/test_plugin.py holds them to the reference's own build-to-build spread with committed fixtures)
+    plans = re.search(r"MI355 decode plans: (\d+) graph_compute calls ran as one persistent launch", r.stdout + r.stderr)
+    par = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
+    out = {"value": float(m.group(4)), "unit": "tok/s", "us_per_token": float(m.group(3)), "entry": m.group(1), "model": m.group(2),
+           "tokens": 128, "graph_compute_calls_as_one_launch": int(plans.group(1)) if plans else None,
+           "logits_vs_cpu_first_tokens": {"nmse": float(par.group(1)), "max_rel": float(par.group(2))} if par else None,
+           "harness": f"oracle/_ref/{variant}/model_parity (reference libggml host + this repo's plugin via GGML_BACKEND_PATH)"}
+    if m.group(5):
+        out["cpu_backend"] = {"value": float(m.group(6)), "unit": "tok/s", "us_per_token": float(m.group(5)), "tokens": int(m.group(7)),
+                              "kind": "reference", "what": "the same graphs on the reference's CPU backend (ggml_backend_cpu, all host threads)"}
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -520,6 +554,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(specs, a.cpu_seconds)
             except Exception as e:                              # the baseline is a report, never a reason to fail the bench
                 out["cpu_baseline"] = {"error": repr(e)}
+            if plan is not None and a.ftype == "Q4_K_M" and not a.no_plugin:
+                try:
+                    out["graph_compute"] = plugin_graph_compute()
+                except Exception as e:
+                    out["graph_compute"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -6,12 +6,21 @@
 // vtables of ggml-backend-impl.h (reg :191-207, device :137-185, buffer type :17-35, buffer :41-66,
 // backend :87-124) in plain C++ over the C-ABI of libmi355q.so (include/mi355q.h): no HIP code here.
 //
-// Scope: the quantized MUL_MAT / MUL_MAT_ID hot path.  supports_op is true for
-//   * GGML_OP_MUL_MAT    with quantized src0 (the 19 types of mi355q_type_supported), f32 src1, f32 dst
-//   * GGML_OP_MUL_MAT_ID with the same src0 types
+// Scope: the quantized MUL_MAT / MUL_MAT_ID hot path and, so that a decode graph stays resident on the
+// device, the f32 / f16 ops between those matmuls.  supports_op is true for
+//   * GGML_OP_MUL_MAT    with quantized src0 (the 19 types of mi355q_type_supported) or f16 / f32 src0, f32 src1, f32 dst
+//   * GGML_OP_MUL_MAT_ID with the same quantized src0 types (expert ids stay on the device)
+//   * ADD SUB MUL DIV SCALE, UNARY (SILU RELU SIGMOID TANH NEG ABS), RMS_NORM, CPY CONT DUP (f32 <-> f16), GET_ROWS, SOFT_MAX, ROPE,
+//     FLASH_ATTN_EXT (f16 K / V), ARGSORT, SUM_ROWS -- the variants a llama / mixtral graph uses (mi355_supports_op lists them)
 //   * the no-op view ops NONE / RESHAPE / VIEW / PERMUTE / TRANSPOSE on our own buffers
 // everything else stays on the CPU backend.  The fork's own DSP backend (ggml/src/ggml-dsp/ggml-dsp.cpp)
 // is the structural template for where each hook goes; none of its code is reused.
+//
+// graph_compute (ggml_backend_i.graph_compute, :109): a one-token decode graph is matched against the llama decode patterns and compiled
+// into a decode plan -- ONE persistent kernel launch per token (decode-plan.inc, mi355q_plan_*); plans are cached per graph key.  Graphs
+// the matcher declines are issued node by node with fused groups, captured into a launch graph at their second sighting and replayed.
+// Asynchronous interface: set/get/cpy_tensor_async, event_record / event_wait, device events, a pinned host buffer type; cpy_tensor_async
+// between two MI355 devices is a peer copy ordered by an event (the layer-split hop of ggml_backend_sched).
 //
 // Device layout of quantized tensors: set_tensor converts canonical ggml rows into the planar device rows
 // of libmi355q (same row size and stride; only the byte order inside a row changes), get_tensor converts

@@ -29,6 +29,9 @@ bool mmq_i8_supported(int type, int64_t k);
 int launch_mmq_i8_multi(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
                         void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare, const MoeTiles * moe = nullptr);
 size_t mmq_i8_split_workspace(int64_t m, int64_t n, int64_t k, int n_cu);
+bool mmq_q80_supported(int type, int64_t k);
+int launch_mmq_q80_multi(const mi355q_mat * mats, int n_mats, const float * x, int64_t x_stride, int64_t n, int64_t k,
+                         void * workspace, size_t workspace_bytes, int n_cu, hipStream_t stream, bool prepare, bool round_even, const MoeTiles * moe = nullptr);
 
 // tier choice for planar rows: GEMV (exact integer dot, fused quantizer) up to 8 activation rows, MFMA tier above
 static bool use_mmq(int type, int64_t n, int64_t k, int flags) {
@@ -116,7 +119,11 @@ __global__ void __launch_bounds__(256) k_moe_scatter(const float * __restrict__ 
     for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = src[i];
 }
 constexpr int64_t MOE_GROUPED_MIN_PAIRS = 17;      // below: one GEMV column per pair with the ids read on the device
-static int moe_tile(int64_t pairs, int64_t n_expert) { return pairs / (n_expert > 0 ? n_expert : 1) >= 192 ? 128 : 64; }
+static int moe_tile(int64_t pairs, int64_t n_expert) {
+    static const int forced = getenv("MI355Q_MOE_TILE") ? atoi(getenv("MI355Q_MOE_TILE")) : 0;      // dev: 64 / 128
+    if (forced == 64 || forced == 128) return forced;
+    return pairs / (n_expert > 0 ? n_expert : 1) >= 192 ? 128 : 64;
+}
 static int64_t moe_slots(int64_t pairs, int64_t n_expert) {     // gathered rows incl. the alignment padding of every segment, a multiple of 128
     const int tile = moe_tile(pairs, n_expert);
     return (pairs + n_expert * (tile - 1) + 127) / 128 * 128;
@@ -336,9 +343,16 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
             mi355q_mat i8m[4]; int n_i8 = 0;                 // ... and ONE grid: their row blocks are concatenated
             for (int i = 0; i < n_mats; ++i) if (i8_ok && mmq_i8_supported(mats[i].type, k) && mats[i].m > 0) i8m[n_i8++] = mats[i];
             if (n_i8 > 0) MQ_TRY(launch_mmq_i8_multi(i8m, n_i8, x, x_stride, n, k, workspace, workspace_bytes, cu_count(), st, true));
+            // Q8_0: integer matrix cores on Q8_0-quantized activations, the CPU's two f32 operations per block in its block order (mmq_q80.hip):
+            // bit-identical to the scalar CPU backend at every batch size
+            static const bool no_q80 = getenv("MI355Q_NO_MMQ_Q80") != nullptr;
+            const bool q80_ok = !no_q80 && !(((uintptr_t) x | (uintptr_t) x_stride) & 15);
+            mi355q_mat q8m[4]; int n_q8 = 0;
+            for (int i = 0; i < n_mats; ++i) if (q80_ok && mmq_q80_supported(mats[i].type, k) && mats[i].m > 0) q8m[n_q8++] = mats[i];
+            if (n_q8 > 0) MQ_TRY(launch_mmq_q80_multi(q8m, n_q8, x, x_stride, n, k, workspace, workspace_bytes, cu_count(), st, true, (flags & MI355Q_FLAG_ROUND_EVEN) != 0));
             bool first = true;
             for (int i = 0; i < n_mats; ++i)
-                if (!(i8_ok && mmq_i8_supported(mats[i].type, k))) {
+                if (!(i8_ok && mmq_i8_supported(mats[i].type, k)) && !(q80_ok && mmq_q80_supported(mats[i].type, k))) {
                     MQ_TRY(launch_mmq_bf16(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, workspace_bytes, cu_count(), st, first));
                     first = false;
                 }
@@ -420,9 +434,13 @@ int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert
         hipLaunchKernelGGL(k_moe_gather, dim3((unsigned) slots), dim3(256), 0, st, (const char *) x, x_stride1, x_stride2, (int) n_used, (int) x_ne1, d_order, xg, k);
         const MoeTiles mt = { d_tile, d_seg_end, expert_stride, tile, 0 };
         static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
+        static const bool no_q80g = getenv("MI355Q_NO_MMQ_Q80") != nullptr;
         if (!no_i8 && mmq_i8_supported(type, k)) {
             const mi355q_mat one = { type, w, w_stride, yg, 4 * m, m };
             MQ_TRY(launch_mmq_i8_multi(&one, 1, xg, 4 * k, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
+        } else if (!no_q80g && mmq_q80_supported(type, k)) {
+            const mi355q_mat one = { type, w, w_stride, yg, 4 * m, m };
+            MQ_TRY(launch_mmq_q80_multi(&one, 1, xg, 4 * k, slots, k, wsp, ws_left, cu_count(), st, true, (flags & MI355Q_FLAG_ROUND_EVEN) != 0, &mt));
         } else {
             MQ_TRY(launch_mmq_bf16(type, w, w_stride, xg, 4 * k, yg, 4 * m, m, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
         }

@@ -133,7 +133,7 @@ struct Streamer {
     }
     __device__ __forceinline__ void prime(const GemvArgs & a, int r_lo, int r_hi_, int k, int wave, int lane, int64_t w_off, int64_t y_off) {
         r_hi = r_hi_;
-        nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
+        nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? k >> 5 : k >> 8;
         nchunks = row_chunks(T, k); steps = (nchunks + 63) >> 6;
         ld_gr = cs_gr = r_lo + wave; ld_s = cs_s = 0;
         if (ld_gr < r_hi) { resolve_ld(a, w_off); resolve_cs(a, y_off); }
@@ -219,8 +219,8 @@ k_gemv_fast(const GemvArgs a) {
 // ------------------------------------------------------------------------------------------------
 static int family_of(int type) {
     switch (type) {
-    case MI355Q_TYPE_Q4_K: case MI355Q_TYPE_Q5_K: case MI355Q_TYPE_Q6_K: return FAM_Q8K;
-    case MI355Q_TYPE_Q8_0: case MI355Q_TYPE_Q4_0: return FAM_Q80;
+    case MI355Q_TYPE_Q4_K: case MI355Q_TYPE_Q5_K: case MI355Q_TYPE_Q6_K: case MI355Q_TYPE_IQ4_XS: return FAM_Q8K;
+    case MI355Q_TYPE_Q8_0: case MI355Q_TYPE_Q4_0: case MI355Q_TYPE_IQ4_NL: return FAM_Q80;
     default: return -1;
     }
 }
@@ -347,9 +347,12 @@ static int launch_gemv_fast_typed(const mi355q_mat * mats, int n_mats, const flo
         switch (wt) {
         case MI355Q_TYPE_Q4_K: return launch_cols<FAM_Q8K, MI355Q_TYPE_Q4_K, false>(a, ncols, g, lds_bytes, stream);
         case MI355Q_TYPE_Q6_K: return launch_cols<FAM_Q8K, MI355Q_TYPE_Q6_K, false>(a, ncols, g, lds_bytes, stream);
+        case MI355Q_TYPE_IQ4_XS: return launch_cols<FAM_Q8K, MI355Q_TYPE_IQ4_XS, false>(a, ncols, g, lds_bytes, stream);
         default:               return launch_cols<FAM_Q8K, MI355Q_TYPE_Q5_K, false>(a, ncols, g, lds_bytes, stream);
         }
     }
+    if (wt == MI355Q_TYPE_IQ4_NL) return even ? launch_cols<FAM_Q80, MI355Q_TYPE_IQ4_NL, true>(a, ncols, g, lds_bytes, stream)
+                                              : launch_cols<FAM_Q80, MI355Q_TYPE_IQ4_NL, false>(a, ncols, g, lds_bytes, stream);
     if (even) return wt == MI355Q_TYPE_Q8_0 ? launch_cols<FAM_Q80, MI355Q_TYPE_Q8_0, true>(a, ncols, g, lds_bytes, stream)
                                             : launch_cols<FAM_Q80, MI355Q_TYPE_Q4_0, true>(a, ncols, g, lds_bytes, stream);
     return wt == MI355Q_TYPE_Q8_0 ? launch_cols<FAM_Q80, MI355Q_TYPE_Q8_0, false>(a, ncols, g, lds_bytes, stream)

@@ -18,8 +18,7 @@ constexpr int GEMV_MAX_MATS = 4;
 //   Q8_0 family: q8[k] | d f32 [k/32] (already f16-rounded) | sums i32 [k/32]
 // ------------------------------------------------------------------------------------------------
 // kernel families: which weight types one kernel instantiation can stream (they share the activation image)
-//   FAM_Q8K : Q4_K, Q6_K (Q8_K activations)   FAM_Q80 : Q8_0, Q4_0 (Q8_0 activations)   FAM_Q5K : Q5_K (Q8_K activations;
-//   kept apart so that the in-flight ring of the hot Q4_K/Q6_K kernel needs 10 instead of 14 VGPRs per slot)
+//   FAM_Q8K : Q4_K, Q5_K, Q6_K, IQ4_XS (Q8_K activations)   FAM_Q80 : Q8_0, Q4_0, IQ4_NL (Q8_0 activations)
 enum { FAM_Q8K = 0, FAM_Q80 = 1 };
 __host__ __device__ constexpr bool fam_is_q8k(int fam) { return fam != FAM_Q80; }
 
@@ -202,9 +201,67 @@ template <int NCOLS> struct Consume<MI355Q_TYPE_Q4_0, NCOLS> {
     }
 };
 
+// ---- the non-linear 4-bit formats: a nibble indexes the 16-entry code book kvalues_iq4nl (ggml-common.h; decoded by
+// dequantize_row_iq4_nl / _xs, ggml-quants.c:2434-2475).  Four nibbles held as bytes of a dword become four int8 with two v_perm_b32
+// (each picks among 8 table bytes by the low 3 bits) and one select on bit 3 -- no LDS table, no per-nibble loads.
+__device__ __forceinline__ uint32_t iq4_lut4(uint32_t nib) {
+    // the code book {-127,-104,-83,-65 | -49,-35,-22,-10 | 1,13,25,38 | 53,69,89,113} as little-endian dwords
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t a = __builtin_amdgcn_perm(0xF6EADDCFu, 0xBFAD9881u, sel);      // entries 0..7
+    const uint32_t b = __builtin_amdgcn_perm(0x71594535u, 0x26190D01u, sel);      // entries 8..15
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
+    return (a & ~m) | (b & m);
+}
+
+// ---- IQ4_NL planar: [qs 16*nb][d 2*nb]; a chunk is one 32-block (low nibbles = elements 0..15, high = 16..31)      ggml-common.h block_iq4_nl
+template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_IQ4_NL>(Chunk & ch, const uint8_t * row, int nb, int s, int lane) {
+    ch.q  = ldg16_nt(row + 1024 * s + 16 * lane);
+    ch.dh = *(const uint16_t *) (row + 16 * nb + 128 * s + 2 * lane);
+}
+template <int NCOLS> struct Consume<MI355Q_TYPE_IQ4_NL, NCOLS> {
+    static __device__ __forceinline__ void run(const Chunk & ch, int s, int lane, const ActView * av, float * acc) {
+        const uint32_t qw[4] = { ch.q.x, ch.q.y, ch.q.z, ch.q.w };
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lo[i] = iq4_lut4(qw[i] & 0x0F0F0F0Fu); hi[i] = iq4_lut4((qw[i] >> 4) & 0x0F0F0F0Fu); }
+        const float dw = h2f(ch.dh);
+        const int c = 64 * s + lane;
+#pragma unroll
+        for (int n = 0; n < NCOLS; ++n) {
+            const int t = dot16(lo, av[n].q16(32 * c)) + dot16(hi, av[n].q16(32 * c + 16));
+            acc[n] += (av[n].d0(c) * dw) * (float) t;         // CPU: d = d_y * d_x; sumf += d * (sumi1 + sumi2)   (ggml-cpu-quants.c ggml_vec_dot_iq4_nl_q8_0)
+        }
+    }
+};
+
+// ---- IQ4_XS planar: [qs 128*nb][hdr(d, scales_h, scales_l[4]) 8*nb]; a chunk is one 32-element sub-block            ggml-common.h block_iq4_xs
+template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_IQ4_XS>(Chunk & ch, const uint8_t * row, int nb, int s, int lane) {
+    ch.q = ldg16_nt(row + 1024 * s + 16 * lane);
+    const uint2 h = *(const uint2 *) (row + 128 * nb + 64 * s + 8 * (lane >> 3));
+    ch.a.x = h.x; ch.a.y = h.y;
+}
+template <int NCOLS> struct Consume<MI355Q_TYPE_IQ4_XS, NCOLS> {
+    static __device__ __forceinline__ void run(const Chunk & ch, int s, int lane, const ActView * av, float * acc) {
+        const int j = lane & 7, b = 8 * s + (lane >> 3);
+        const uint32_t qw[4] = { ch.q.x, ch.q.y, ch.q.z, ch.q.w };
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lo[i] = iq4_lut4(qw[i] & 0x0F0F0F0Fu); hi[i] = iq4_lut4((qw[i] >> 4) & 0x0F0F0F0Fu); }
+        const float d = h2f(ch.a.x & 0xFFFFu);
+        const uint32_t sh = ch.a.x >> 16;                      // scales_h
+        const int ls = (int) ((ch.a.y >> (4 * j)) & 0xFu) | (int) (((sh >> (2 * j)) & 3u) << 4);     // scales_l nibble j | 2 high bits
+        const int e = 2048 * s + 256 * (lane >> 3) + 32 * j;
+#pragma unroll
+        for (int n = 0; n < NCOLS; ++n) {
+            const int t = dot16(lo, av[n].q16(e)) + dot16(hi, av[n].q16(e + 16));
+            acc[n] += ((d * av[n].dK(b)) * (float) (ls - 32)) * (float) t;     // CPU: d4d8 = d_x * d_y; d1 = d4d8 * (ls - 32); sumf += d1 * (sumi1 + sumi2)
+        }
+    }
+};
+
 // chunks per row for a type
 __host__ __device__ __forceinline__ int row_chunks(int type, int k) {
-    return type == MI355Q_TYPE_Q8_0 ? k / 16 : k / 32;       // Q4_0: one per 32-block; K-quants: 8 per 256-block
+    return type == MI355Q_TYPE_Q8_0 ? k / 16 : k / 32;       // Q4_0 / IQ4_NL: one per 32-block; K-quants / IQ4_XS: 8 per 256-block
 }
 
 // ------------------------------------------------------------------------------------------------

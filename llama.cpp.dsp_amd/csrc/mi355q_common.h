@@ -46,8 +46,8 @@ inline const TypeInfo * type_info(int type) {   // host only
         { MI355Q_TYPE_Q4_K,   256, 144, MI355Q_TYPE_Q8_K, 2, {{16, 128}, {0, 16}, {0, 0}, {0, 0}},        1 },
         { MI355Q_TYPE_Q5_K,   256, 176, MI355Q_TYPE_Q8_K, 3, {{48, 128}, {16, 32}, {0, 16}, {0, 0}},      1 },
         { MI355Q_TYPE_Q6_K,   256, 210, MI355Q_TYPE_Q8_K, 4, {{0, 128}, {128, 64}, {192, 16}, {208, 2}},  1 },
-        { MI355Q_TYPE_IQ4_NL, 32,  18, MI355Q_TYPE_Q8_0, 2, {{2, 16}, {0, 2}, {0, 0}, {0, 0}},            0 },
-        { MI355Q_TYPE_IQ4_XS, 256, 136, MI355Q_TYPE_Q8_K, 2, {{8, 128}, {0, 8}, {0, 0}, {0, 0}},          0 },
+        { MI355Q_TYPE_IQ4_NL, 32,  18, MI355Q_TYPE_Q8_0, 2, {{2, 16}, {0, 2}, {0, 0}, {0, 0}},            1 },
+        { MI355Q_TYPE_IQ4_XS, 256, 136, MI355Q_TYPE_Q8_K, 2, {{8, 128}, {0, 8}, {0, 0}, {0, 0}},          1 },
         // code-book formats: canonical layout, generic tier (code books: iq_tables.h)
         { MI355Q_TYPE_IQ2_XXS, 256, 66,  MI355Q_TYPE_Q8_K, 1, {{0, 66}, {0, 0}, {0, 0}, {0, 0}},          0 },
         { MI355Q_TYPE_IQ2_XS,  256, 74,  MI355Q_TYPE_Q8_K, 1, {{0, 74}, {0, 0}, {0, 0}, {0, 0}},          0 },

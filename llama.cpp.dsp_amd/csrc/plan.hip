@@ -1018,7 +1018,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             if (done[i]) continue;
             const int type = in.mats[i].type;
             const int fam = gemv_fast_family(type);
-            if (fam < 0 || !mi355q_weights_are_planar(type, in.k)) { mi355q_set_error("plan_create: weight type / k has no planar streaming kernel"); return MI355Q_ERR_UNSUPPORTED; }
+            if (fam < 0 || !(tbit(type) & SET_ALL) || !mi355q_weights_are_planar(type, in.k)) { mi355q_set_error("plan_create: weight type / k has no planar streaming kernel in the plan"); return MI355Q_ERR_UNSUPPORTED; }
             PlanStage p = {};
             p.kind = PLAN_K_GEMV; p.tag_off = (unsigned) v.size() + 1;
             int64_t rows = 0; int n = 0;

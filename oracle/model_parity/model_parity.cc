@@ -26,6 +26,7 @@
 //     --bench N                    afterwards: N more decode steps on the device alone, timed end to end per token (graph build, allocation,
 //                                  input upload, graph_compute, synchronize, logits download), and the same on the CPU backend for <= 8 steps
 //     --no-cpu                     skip the CPU backend (with --bench: timing only)
+//     --time-cpu                   with --check: build the CPU model too and time it in the --bench leg
 // exit code 0 = every node supported by the device(s) and, for every step, max|logit - ref| <= 1e-3 * max|ref|  (north-star bound) and NMSE <= 1e-5
 //               (or 3 x the reference's own spread where --noise shows it to be larger).
 #include <chrono>
@@ -195,7 +196,7 @@ struct Runner {                         // one model instance + how its graphs a
 int main(int argc, char ** argv) {
     Dims d;
     std::string preset = "small", devs = "MI355_0", dump, check, noise;
-    int tokens = 16, prompt = 0, bench = 0; bool use_sched = false, no_cpu = false;
+    int tokens = 16, prompt = 0, bench = 0; bool use_sched = false, no_cpu = false, time_cpu = false;
     d.n_layer = 4; d.n_vocab = 32000;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -203,7 +204,7 @@ int main(int argc, char ** argv) {
         if (a == "--preset") preset = next(); else if (a == "--layers") d.n_layer = atoi(next().c_str()); else if (a == "--vocab") d.n_vocab = atoi(next().c_str());
         else if (a == "--tokens") tokens = atoi(next().c_str()); else if (a == "--prompt") prompt = atoi(next().c_str()); else if (a == "--devs") devs = next();
         else if (a == "--fa") d.fa = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--noise") noise = next(); else if (a == "--bench") bench = atoi(next().c_str());
-        else if (a == "--sched") use_sched = true; else if (a == "--no-cpu") no_cpu = true;
+        else if (a == "--sched") use_sched = true; else if (a == "--no-cpu") no_cpu = true; else if (a == "--time-cpu") time_cpu = true;
         else if (a == "--moe") { const std::string v = next(); d.n_expert = atoi(v.c_str()); d.n_used = v.find(',') == std::string::npos ? 2 : atoi(v.c_str() + v.find(',') + 1); }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 3; }
     }
@@ -213,7 +214,7 @@ int main(int argc, char ** argv) {
     else if (preset != "small") { fprintf(stderr, "unknown preset\n"); return 3; }
     d.n_ctx = GGML_PAD(prompt + tokens + bench + 8, 256);
     const bool dump_only = !dump.empty();
-    if (!check.empty()) no_cpu = true;
+    if (!check.empty()) no_cpu = !time_cpu;          // with a fixture the CPU backend is only needed when its time is asked for (it then also runs the steps: argmax)
 
     ggml_backend_load_all();
     Runner dev, cpu;

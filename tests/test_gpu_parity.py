@@ -268,10 +268,13 @@ def test_mfma_tier(G, torch, orc, t, shape):
     # (2) against the exact product of the dequantized weights and the f32 activations (float64)
     exact = x.astype(np.float64) @ orc.dequantize(t, w, K).astype(np.float64).T
     e = nmse(y, exact)
-    if t == oracle.Q4_K:
-        # integer tier (csrc/mmq_i8.hip): the CPU's own arithmetic -- Q8_K activations, exact integer block sums -- so it matches the
-        # oracle to f32 summation order, and its distance from the exact product is the CPU's Q8_K quantization noise (~5e-5)
+    if t in (oracle.Q4_K, oracle.Q8_0):
+        # integer tiers (csrc/mmq_i8.hip, csrc/mmq_q80.hip): the CPU's own arithmetic -- Q8_K / Q8_0 activations, exact integer block sums --
+        # so they match the oracle to f32 summation order (Q8_0: bit for bit, test_q8_0_prefill_is_bit_exact), and their distance from the
+        # exact product is the CPU's own activation quantization noise (~5e-5 / ~3e-5)
         check_close(y[np.ix_(cols, rows)], ref)
+        if t == oracle.Q8_0 and K % 256 == 0:
+            assert np.array_equal(y[np.ix_(cols, rows)].view(np.uint32), ref.view(np.uint32))
         assert e <= 1.5e-4, f"NMSE vs exact {e:.3e}"
         e_cpu = nmse(ref, exact[np.ix_(cols, rows)])
         assert e <= 3 * e_cpu + 1e-6, f"NMSE vs exact {e:.3e}, the CPU arithmetic itself {e_cpu:.3e}"
@@ -281,6 +284,41 @@ def test_mfma_tier(G, torch, orc, t, shape):
     if N <= 64:
         yg = gpu_mul_mat(G, torch, t, w, x, M, K, flags=0x4)          # MI355Q_FLAG_FORCE_GEMV
         check_close(yg[np.ix_(cols, rows)], ref)
+
+
+@pytest.mark.parametrize("shape", [(128, 9, 2048), (200, 130, 2048), (1024, 512, 4096), (96, 33, 14336), (12288, 160, 1024)], ids=str)
+@pytest.mark.parametrize("round_even", [False, True], ids=["round_away", "round_even"])
+def test_q8_0_prefill_is_bit_exact(G, torch, orc, shape, round_even):
+    """north_star: "bit-exact for Q8_0 integer dot".  At N > 8 the Q8_0 tier (csrc/mmq_q80.hip) takes the exact int32 block sums from the integer
+    matrix cores and applies the CPU's two f32 operations per block in the CPU's block order (ggml_vec_dot_q8_0_q8_0 scalar tail), so every
+    output equals the scalar CPU backend bit for bit -- for both activation rounding rules (roundf: quantize_row_q8_0_ref; rint: the AVX2 path)."""
+    M, N, K = shape
+    t = oracle.Q8_0
+    rng = np.random.default_rng(M + N + K)
+    w = quantized_weights(t, M, K, rng)
+    x = (rng.standard_normal((N, K)) * rng.uniform(0.2, 3.0)).astype(np.float32)
+    x[N // 2, 32:64] = 0.0                                  # an all-zero activation block: d = 0, id = 0
+    x[0, :32] = np.arange(32, dtype=np.float32) - 15.5      # exact .5 ties after scaling: the two rounding rules differ here
+    y = gpu_mul_mat(G, torch, t, w, x, M, K, flags=0x1 if round_even else 0x0)
+    rows = np.unique(np.concatenate([rng.integers(0, M, 96), [0, M - 1]])); cols = np.unique(np.concatenate([rng.integers(0, N, 24), [0, N - 1, N // 2]]))
+    ref = orc.mul_mat(t, w[rows], x[cols], len(rows), len(cols), K, round_mode=oracle.ROUND_EVEN if round_even else oracle.ROUND_AWAY)
+    assert np.array_equal(y[np.ix_(cols, rows)].view(np.uint32), ref.view(np.uint32))
+
+
+def test_q8_0_prefill_multi_and_unaligned_fall_back(G, torch, orc):
+    """QKV-style multi launch shares one quantized activation image and stays bit-exact; K % 256 != 0 or an unaligned output falls to other tiers."""
+    t = oracle.Q8_0
+    rng = np.random.default_rng(80)
+    K, N = 4096, 77
+    specs = [96, 40, 24]
+    hosts = [quantized_weights(t, m, K, rng) for m in specs]
+    ws = [G.QWeight.from_host(t, h, m, K) for m, h in zip(specs, hosts)]
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    for ym, h, m in zip(G.mul_mat_multi(ws, torch.from_numpy(x).cuda()), hosts, specs):
+        assert np.array_equal(ym.cpu().numpy().view(np.uint32), orc.mul_mat(t, h, x, m, N, K).view(np.uint32))
+    K = 384                                                # 12 blocks: not a multiple of the 256-k step
+    w = quantized_weights(t, 64, K, rng); x = rng.standard_normal((20, K)).astype(np.float32)
+    check(G, t, K, 20, gpu_mul_mat(G, torch, t, w, x, 64, K), orc.mul_mat(t, w, x, 64, 20, K), "K=384")
 
 
 def test_mfma_tier_ragged_and_alignment_fallback(G, torch, orc):
@@ -327,8 +365,8 @@ def test_multi_equals_single(G, torch, orc):
 @pytest.mark.parametrize("cfg", [(4, 1, 1), (8, 2, 1), (8, 4, 5), (4, 2, 32), (8, 2, 160)], ids=str)
 def test_mul_mat_id(G, torch, orc, t, cfg):
     """(n_expert, n_used, n_tokens).  Up to 16 (token, slot) pairs every pair is one exact GEMV column with the ids read on the device;
-    above that the rows are grouped by expert and each group goes through the ordinary mul_mat tiers (csrc/api.hip), i.e. groups of
-    more than 8 rows use the matrix cores: Q4_K still reproduces the CPU arithmetic, the bf16 tier is held to the reference's op bound."""
+    above that the pairs are counting-sorted by expert ON THE DEVICE and one launch of the matrix-core tier walks all experts (csrc/api.hip):
+    Q4_K and Q8_0 still reproduce the CPU arithmetic (integer tiers; Q8_0 bit for bit), the bf16 tier is held to the reference's op bound."""
     ne, nu, nt = cfg
     rng = np.random.default_rng(17 * t + ne + nu + nt)
     for K, M in ((256, 512), (2048, 96)):
@@ -339,8 +377,8 @@ def test_mul_mat_id(G, torch, orc, t, cfg):
             b = rng.uniform(-1, 1, (nt, b1, K)).astype(np.float32)
             y = G.mul_mat_id(w, torch.from_numpy(b).cuda(), torch.from_numpy(ids).cuda()).cpu().numpy()
             ref = orc.mul_mat_id(t, as_, b, ids, M, K, ne)
-            biggest = int(np.bincount(ids.ravel(), minlength=ne).max())
-            if nu * nt >= 17 and t != oracle.Q4_K and on_mfma_tier(G, t, K, biggest) and M % 4 == 0:
+            # from 17 pairs on the rows are grouped by expert on the device and ALL groups run on the matrix-core tier in one launch
+            if nu * nt >= 17 and t not in (oracle.Q4_K, oracle.Q8_0) and on_mfma_tier(G, t, K, 9) and M % 4 == 0:
                 assert np.isfinite(y).all() and nmse(y, ref) <= 5e-4, f"{ids_t(t)} {cfg} K={K} b1={b1}"
             else:
                 check_close(y, ref, f"{ids_t(t)} {cfg} K={K} b1={b1}")

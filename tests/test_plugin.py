@@ -283,6 +283,24 @@ def test_whole_model_decode_equal_to_cpu(mode):
 
 @pytest.mark.gpu
 @needs_plugin
+def test_whole_model_two_devices_through_the_scheduler():
+    """--split-mode layer as llama.cpp does it: ONE process, ggml_backend_sched over two devices of the plugin (the one card of the test box presented
+    twice, MI355_DUP_DEVICES=2) + the CPU backend.  The scheduler cuts the 4-layer model in two splits; the boundary activation travels through the
+    plugin's cpy_tensor_async (peer copy + event), each half runs as its own decode plan, and the logits equal the CPU's (bound: see the fixture test)."""
+    if _model_parity() is None or not _model_parity().exists():
+        pytest.skip("oracle/_ref/*/model_parity not built")
+    r = _run_model(["--preset", "small", "--layers", "4", "--vocab", "8192", "--tokens", "8", "--devs", "MI355_0,MI355_1", "--sched"], {"MI355_DUP_DEVICES": "2"})
+    print(r.stdout[-2500:], r.stderr[-1200:])
+    m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ARGMAX DIFFERS" not in r.stdout
+    assert re.search(r"scheduler: 2 splits over 3 backends", r.stdout), r.stdout[-1500:]
+    plans = re.findall(r"decode plans: (\d+) graph_compute calls ran as one persistent launch", r.stderr)
+    assert [int(v) for v in plans] == [8, 8], plans                # both devices ran every token of their half as one launch
+
+
+@pytest.mark.gpu
+@needs_plugin
 def test_decode_layer_plan_with_suffix_nodes():
     """layer_parity's single-layer graph ends with the residual ADD (no norm behind it): the plan covers everything before it, the ADD is
     issued as a normal node after the launch and reads the plan's plain outputs.  40 steps against the CPU backend, KV cache included."""

@@ -30,8 +30,10 @@ def main():
     pdir = sys.argv[3] if len(sys.argv) > 3 else None
     out = ROOT / "profiles"
     out.mkdir(exist_ok=True)
-    stats = glob.glob(f"{kdir}/**/*kernel_stats.csv", recursive=True)[0]
-    trace = glob.glob(f"{kdir}/**/*kernel_trace.csv", recursive=True)[0]
+    import os
+    newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)       # (gpurun merges every pass into the same local directory)
+    stats = newest(f"{kdir}/**/*kernel_stats.csv")
+    trace = newest(f"{kdir}/**/*kernel_trace.csv")
     rows = list(csv.DictReader(open(stats)))
     with open(out / f"{tag}_kernel_stats.csv", "w") as f:
         w = csv.writer(f)
@@ -52,7 +54,7 @@ def main():
             v.sort()
             f.write(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {k[4]} | {len(v)} | {v[0]/1e3:.2f} | {v[len(v)//2]/1e3:.2f} | {sum(v)/len(v)/1e3:.2f} | {v[-1]/1e3:.2f} |\n")
     if pdir:
-        cc = glob.glob(f"{pdir}/**/*counter_collection.csv", recursive=True)[0]
+        cc = newest(f"{pdir}/**/*counter_collection.csv")
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(cc)):
             if ("k_gemv_fast" in r["Kernel_Name"] or "k_plan" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
@@ -66,11 +68,14 @@ def main():
                 f.write(f"| {k} | {len(v)} | " + ", ".join(f"{mb} ({n})" for mb, n in sorted(c.items())[:14]) + " |\n")
             import json, statistics
             traffic = {k: int(statistics.median(v) * 2 * 1024) for k, v in agg.items() if k.startswith("k_plan")}
+            from bench import kernel_source_sha16           # the measurement is quoted by bench.py only while the kernel sources are unchanged
             (out / f"{tag}_traffic.json").write_text(json.dumps({"unit": "bytes per launch", "source": f"profiles/{tag}_pmc_fetch_size.md",
+                "kernel_source_sha16": kernel_source_sha16(),
                 "method": "rocprofv3 --pmc FETCH_SIZE (own pass of `bench.py --steps 8`), median over launches, KiB x 1024 x 2 (gfx950 wide-read correction)",
                 "kernels": traffic}, indent=1) + "\n")
             f.write("\nAlgorithmic MB per launch of the Llama-3-8B Q4_K_M token (bench.py): wq+wk(+wv) 11.8/14.2, wv(q6_K) 3.4, wo 9.4, "
-                    "gate|up 66.1, down 33.0 (q4_K) / 48.2 (q6_K), output 430.9; the whole token (one k_plan launch) 4616.3.\n")
+                    "gate|up 66.1, down 33.0 (q4_K) / 48.2 (q6_K), output 430.9; the whole token (one k_plan launch) 4616.3 of weights "
+                    "+ 0.131 per cached position of K and V (32 layers x 2 x 1024 f16 x 2 B).\n")
     print("wrote", sorted(p.name for p in out.glob(f"{tag}_*")))
 
 
