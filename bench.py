@@ -347,17 +347,34 @@ def main():
     import torch.distributed as dist
     import ggml_mi355 as g
     from ggml_mi355 import workloads as wl
+    rehearse = os.environ.get("MI355Q_BENCH_REHEARSE") == "1" and not a.dry_run
+
+    def p2p_send(t, dst):
+        dist.send(t.cpu() if rehearse else t, dst=dst)
+
+    def p2p_recv(t, src):
+        if rehearse:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(h, src=src)
+            t.copy_(h)
+        else:
+            dist.recv(t, src=src)
 
     if a.dry_run:
         device = torch.device("cpu")
         if world > 1:
             dist.init_process_group("gloo")
     else:
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        # MI355Q_BENCH_REHEARSE=1 (tests/test_gpu_bench.py): every rank on GPU 0 and the hop through gloo / host memory, so that the
+        # multi-rank code path (per-rank plans, boundary tensors, hop and completion protocol) runs on a one-GPU box.  Never a measurement.
+        torch.cuda.set_device(0 if rehearse else local_rank)
+        device = torch.device("cuda", 0 if rehearse else local_rank)
         g.lib()                                     # fail loudly if the HIP extension is missing
         if world > 1:
-            dist.init_process_group("nccl", device_id=device)
+            if rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=device)
 
     cfg = wl.MODELS[a.model]
     specs = wl.llama_matmuls(cfg, a.ftype)
@@ -367,13 +384,25 @@ def main():
 
     act = torch.zeros((1, cfg["n_embd"]), dtype=torch.float32, device=device)
 
+    def token_done(flag):
+        """llama-bench generates token t+1 only after llama_synchronize() has seen token t leave the LAST device (examples/llama-bench/llama-bench.cpp:1454-1468
+        test_gen: llama_decode, llama_synchronize, next token).  With one process per GPU that wait is a one-word message from the last stage back to
+        the first: without it the stages would overlap different tokens and the "scaling" would be pipeline throughput no decode loop can have."""
+        if world > 1:
+            if rank == world - 1:
+                p2p_send(flag, 0)
+            elif rank == 0:
+                p2p_recv(flag, world - 1)
+
     if a.dry_run:
         stage = None
+        done = torch.zeros(1, dtype=torch.int32)
         def token():
             if world > 1 and rank > 0:
                 dist.recv(act, src=rank - 1)
             if world > 1 and rank < world - 1:
                 dist.send(act, dst=rank + 1)
+            token_done(done)
     else:
         stage = Stage(torch, g, mine, not a.no_fuse, device)
         launch = "eager" if a.no_graph else a.launch
@@ -393,21 +422,24 @@ def main():
             if world == 1:
                 verify_token0(torch, g, stage, plan, cfg, act)
         act_out = torch.zeros_like(act)
+        done = torch.zeros(1, dtype=torch.int32, device=device)
         tok = [0]
         def token():
             if world > 1 and rank > 0:
-                dist.recv(act, src=rank - 1)                    # boundary activation from the previous stage: the first norm of this rank reads it
+                p2p_recv(act, rank - 1)                         # boundary activation from the previous stage: the first norm of this rank reads it
             if plan is not None:
                 stage.set_token(tok[0] % n_ctx); tok[0] += 1
                 plan.run()
                 if world > 1 and rank < world - 1:
                     torch.add(stage.boundary[0], stage.boundary[1], out=act_out)       # the layer output h = ffn_inp + ffn_down
-                    dist.send(act_out, dst=rank + 1)
+                    p2p_send(act_out, rank + 1)
+                token_done(done)
                 torch.cuda.current_stream().synchronize()       # llama-bench: llama_decode + llama_synchronize per generated token
             else:
                 (graph.replay if graph is not None else stage.run)()
                 if world > 1 and rank < world - 1:
-                    dist.send(act, dst=rank + 1)
+                    p2p_send(act, rank + 1)
+                token_done(done)
 
     def sync():
         if not a.dry_run:
@@ -427,10 +459,15 @@ def main():
         token()
     sync()
     dt = time.perf_counter() - t0
+    if not a.dry_run and plan is not None and plan.status() != 0:
+        raise RuntimeError(f"rank {rank}: decode plan aborted (a poll timed out)")
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if rank == world - 1 and not a.dry_run and getattr(stage, "logits", None) is not None:
+            if not bool(torch.isfinite(stage.logits).all()):
+                raise RuntimeError("the last stage's logits are not finite")
 
     out = {
         "metric": "llama-bench tg128 tok/s (decode step at the C-ABI of the quantized-matmul hot path), " + {"llama3-8b": "Llama-3-8B", "llama3-70b": "Llama-3-70B", "mixtral-8x7b": "Mixtral-8x7B"}[a.model] + " " + a.ftype,
@@ -445,7 +482,7 @@ def main():
                                   "graph": "one launch per matmul step, hipGraph replay; non-matmul graph ops not executed",
                                   "eager": "one launch per matmul step, eager; non-matmul graph ops not executed"}[launch if not a.dry_run else "eager"],
                    "bytes_per_token": total_bytes,
-                   "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs (RCCL send/recv of the boundary activation)"},
+                   "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs (RCCL send/recv of the boundary activation; a token starts when the previous one has left the last GPU, as llama_synchronize makes llama-bench wait)"},
     }
 
     if not a.dry_run and rank == 0:

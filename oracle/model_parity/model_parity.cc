@@ -25,6 +25,7 @@
 //                                  scale.  With --noise the bound is max(north-star bound, 3 x the worst such spread).
 //     --bench N                    afterwards: N more decode steps on the device alone, timed end to end per token (graph build, allocation,
 //                                  input upload, graph_compute, synchronize, logits download), and the same on the CPU backend for <= 8 steps
+//     --pp N                       afterwards: a prompt of N tokens from an empty context on the device, timed end to end (llama-bench pp)
 //     --no-cpu                     skip the CPU backend (with --bench: timing only)
 //     --time-cpu                   with --check: build the CPU model too and time it in the --bench leg
 // exit code 0 = every node supported by the device(s) and, for every step, max|logit - ref| <= 1e-3 * max|ref|  (north-star bound) and NMSE <= 1e-5
@@ -43,7 +44,7 @@
 #include "ggml-alloc.h"
 #include "ggml-backend.h"
 
-struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; int n_expert = 0, n_used = 0; };
+struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; int n_expert = 0, n_used = 0; bool last_only = false; };
 
 struct Layer { ggml_tensor *attn_norm, *ffn_norm, *wq, *wk, *wv, *wo, *wgate, *wup, *wdown, *kc, *vc, *gate_inp; };   // MoE: wgate / wup / wdown are [k, m, n_expert]
 struct Model {
@@ -168,6 +169,8 @@ static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens
     }
     // llm_build_llama tail: only the last token's row goes through the output norm and matrix when decoding one token at a time; a batch
     // keeps every row (llama-bench pp computes all logits' inputs but the harness compares the last row only)
+    // (d.last_only, the --pp timing: the last row alone, as llama_decode does for a llama-bench prompt -- llm_build_llama's inp_out_ids)
+    if (d.last_only && inpL->ne[1] > 1) inpL = ggml_cont(c, ggml_view_2d(c, inpL, inpL->ne[0], 1, inpL->nb[1], (size_t) (inpL->ne[1] - 1) * inpL->nb[1]));
     ggml_tensor * cur = ggml_mul(c, ggml_rms_norm(c, inpL, eps), M.out_norm);
     S.logits = ggml_mul_mat(c, M.output, cur);
     ggml_set_output(S.logits);
@@ -196,14 +199,14 @@ struct Runner {                         // one model instance + how its graphs a
 int main(int argc, char ** argv) {
     Dims d;
     std::string preset = "small", devs = "MI355_0", dump, check, noise;
-    int tokens = 16, prompt = 0, bench = 0; bool use_sched = false, no_cpu = false, time_cpu = false;
+    int tokens = 16, prompt = 0, bench = 0, pp = 0; bool use_sched = false, no_cpu = false, time_cpu = false;
     d.n_layer = 4; d.n_vocab = 32000;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? std::string(argv[++i]) : std::string(); };
         if (a == "--preset") preset = next(); else if (a == "--layers") d.n_layer = atoi(next().c_str()); else if (a == "--vocab") d.n_vocab = atoi(next().c_str());
         else if (a == "--tokens") tokens = atoi(next().c_str()); else if (a == "--prompt") prompt = atoi(next().c_str()); else if (a == "--devs") devs = next();
-        else if (a == "--fa") d.fa = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--noise") noise = next(); else if (a == "--bench") bench = atoi(next().c_str());
+        else if (a == "--fa") d.fa = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--noise") noise = next(); else if (a == "--bench") bench = atoi(next().c_str()); else if (a == "--pp") pp = atoi(next().c_str());
         else if (a == "--sched") use_sched = true; else if (a == "--no-cpu") no_cpu = true; else if (a == "--time-cpu") time_cpu = true;
         else if (a == "--moe") { const std::string v = next(); d.n_expert = atoi(v.c_str()); d.n_used = v.find(',') == std::string::npos ? 2 : atoi(v.c_str() + v.find(',') + 1); }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 3; }
@@ -212,7 +215,7 @@ int main(int argc, char ** argv) {
     else if (preset == "8b") { d.n_embd = 4096; d.n_head = 32; d.n_head_kv = 8; d.hd = 128; d.n_ff = 14336; }
     else if (preset == "70b") { d.n_embd = 8192; d.n_head = 64; d.n_head_kv = 8; d.hd = 128; d.n_ff = 28672; }
     else if (preset != "small") { fprintf(stderr, "unknown preset\n"); return 3; }
-    d.n_ctx = GGML_PAD(prompt + tokens + bench + 8, 256);
+    d.n_ctx = GGML_PAD(std::max(prompt + tokens + bench + 8, pp), 256);
     const bool dump_only = !dump.empty();
     if (!check.empty()) no_cpu = !time_cpu;          // with a fixture the CPU backend is only needed when its time is asked for (it then also runs the steps: argmax)
 
@@ -394,7 +397,10 @@ int main(int argc, char ** argv) {
                 if (run_cpu) for (int i = 1; i < d.n_vocab; ++i) { if (ref[i] > ref[am_r]) am_r = i; if (got[i] > got[am_g]) am_g = i; }
                 double b_nm = 1e-5, b_rel = 1e-3;                       // north-star bound, or 3 x the reference's own worst build-to-build spread over the steps
                 for (size_t t = 0; t < spread_nmse.size(); ++t) { b_nm = std::fmax(b_nm, 3 * spread_nmse[t]); b_rel = std::fmax(b_rel, 3 * spread_rel[t]); }
-                printf("step %2d: n_tokens=%d n_past=%d  logits NMSE %.3e  max|d|/max|ref| %.3e%s", step_no, n, n_past, nm, rel, run_cpu ? (am_r == am_g ? "  argmax equal" : "  ARGMAX DIFFERS") : "");
+                // a different argmax is only a disagreement when the reference itself separates the two candidates by more than the error it is compared within
+                const bool am_close = run_cpu && am_r != am_g && (double) ref[am_r] - (double) ref[am_g] <= 2.0 * md;
+                printf("step %2d: n_tokens=%d n_past=%d  logits NMSE %.3e  max|d|/max|ref| %.3e%s", step_no, n, n_past, nm, rel,
+                       run_cpu ? (am_r == am_g ? "  argmax equal" : am_close ? "  argmax: two candidates closer than the error (tie)" : "  ARGMAX DIFFERS") : "");
                 if ((size_t) step_no < spread_nmse.size()) printf("   [the reference's own builds: NMSE %.3e, max rel %.3e]", spread_nmse[(size_t) step_no], spread_rel[(size_t) step_no]);
                 printf("\n");
                 worst_rel = std::fmax(worst_rel, rel); worst_nmse = std::fmax(worst_nmse, nm);
@@ -440,6 +446,28 @@ int main(int argc, char ** argv) {
                dev.sched ? "sched_graph_compute" : "graph_compute", d.n_layer, d.n_embd, d.n_ff, d.n_vocab, n_past, devs.c_str(), us_dev, 1e6 / us_dev);
         if (n_cpu) printf("; CPU backend %.1f us/token = %.2f tok/s (%d tokens)", us_cpu, 1e6 / us_cpu, n_cpu);
         printf("\n");
+    }
+    if (pp > 0 && !dump_only) {
+        auto time_prompt = [&](Runner & R, int reps) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; ++r) {
+                Step S = build_step(d, R.M, 0, pp);
+                R.alloc(S);
+                std::vector<int> ids(pp); for (auto & t : ids) t = next_token();
+                set_inputs(R, S, ids, 0);
+                R.compute(S);
+                if (R.sched) ggml_backend_sched_synchronize(R.sched); else ggml_backend_synchronize(R.backends[0]);
+                float l0; ggml_backend_tensor_get(S.logits, &l0, 0, 4);
+                ggml_free(S.ctx);
+            }
+            return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        };
+        d.last_only = true;
+        time_prompt(dev, 2);
+        const double us = time_prompt(dev, 5);
+        d.last_only = false;
+        printf("prefill through ggml_backend_%s (n_layer %d, n_embd %d, n_ff %d, n_vocab %d): %d tokens in %.1f us = %.1f tok/s\n",
+               dev.sched ? "sched_graph_compute" : "graph_compute", d.n_layer, d.n_embd, d.n_ff, d.n_vocab, pp, us, pp * 1e6 / us);
     }
     printf("%s\n", ok ? "MODEL PARITY OK" : "MODEL PARITY FAILED");
     for (ggml_backend_t b : dev.backends) ggml_backend_free(b);

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for cfg in 14 18 28; do echo "cfg $cfg"; MI355Q_Q80_CFG=$cfg timeout -k 10 120 python tools/pp_one.py q8_0 14336 4096 512 2>/dev/null; MI355Q_Q80_CFG=$cfg timeout -k 10 120 python tools/pp_one.py q8_0 4096 4096 512 2>/dev/null; MI355Q_Q80_CFG=$cfg timeout -k 10 120 python tools/pp_one.py q8_0 4096 14336 512 2>/dev/null; done
-for cfg in 14 18 28; do MI355Q_Q80_CFG=$cfg timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "q8_0" 2>&1 | tail -2; done
+timeout -k 10 1150 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1; rc=$?
+tail -5 gpurun_out/gpu_tests_full.log | cut -c1-300
+[ $rc -ne 0 ] && { tail -80 gpurun_out/gpu_tests_full.log | cut -c1-300; exit 1; }
 exit 0
