@@ -317,7 +317,7 @@ def plugin_graph_compute(seconds_cap=240):
     if variant is None or not exe.exists() or not plugin.exists():
         return None
     env = dict(os.environ, GGML_BACKEND_PATH=str(plugin), MI355_GRAPH_STATS="1")
-    r = subprocess.run([str(exe), "--preset", "8b", "--layers", "32", "--vocab", "128256", "--tokens", "2", "--bench", "128"], env=env, capture_output=True, text=True, timeout=seconds_cap)
+    r = subprocess.run([str(exe), "--preset", "8b", "--layers", "32", "--vocab", "128256", "--tokens", "2", "--bench", "128", "--pp", "512"], env=env, capture_output=True, text=True, timeout=seconds_cap)
     m = re.search(r"decode through (\S+) \((.*?)\): \S+ ([0-9.]+) us/token = ([0-9.]+) tok/s(?:; CPU backend ([0-9.]+) us/token = ([0-9.]+) tok/s \((\d+) tokens\))?", r.stdout)
     if not m:
         return {"error": f"model_parity exit {r.returncode}", "tail": (r.stdout + r.stderr)[-400:]}
@@ -329,6 +329,13 @@ def plugin_graph_compute(seconds_cap=240):
            "tokens": 128, "graph_compute_calls_as_one_launch": int(plans.group(1)) if plans else None,
            "logits_vs_cpu_first_tokens": {"nmse": float(par.group(1)), "max_rel": float(par.group(2))} if par else None,
            "harness": f"oracle/_ref/{variant}/model_parity (reference libggml host + this repo's plugin via GGML_BACKEND_PATH)"}
+    pp = re.search(r"prefill through \S+ \(.*?\): (\d+) tokens in ([0-9.]+) us = ([0-9.]+) tok/s", r.stdout)
+    if pp:
+        out["pp512"] = {"value": float(pp.group(3)), "unit": "tok/s", "ms": round(float(pp.group(2)) / 1e3, 3),
+                        "what": f"a {pp.group(1)}-token prompt from an empty context through graph_compute (all nodes: norms, rope, KV stores, attention, matmuls; logits of the last token), as llama-bench pp"}
+    hp = re.search(r"graph build ([0-9.]+) us, allocation ([0-9.]+) us, inputs ([0-9.]+) us, graph_compute call ([0-9.]+) us, synchronize \+ logit ([0-9.]+) us", r.stdout)
+    if hp:
+        out["host_phases_us"] = dict(zip(("graph_build", "allocation", "inputs", "graph_compute_call", "synchronize_and_logit"), (float(v) for v in hp.groups())))
     if m.group(5):
         out["cpu_backend"] = {"value": float(m.group(6)), "unit": "tok/s", "us_per_token": float(m.group(5)), "tokens": int(m.group(7)),
                               "kind": "reference", "what": "the same graphs on the reference's CPU backend (ggml_backend_cpu, all host threads)"}

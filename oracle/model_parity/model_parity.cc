@@ -423,29 +423,44 @@ int main(int argc, char ** argv) {
     if (run_cpu || !check.empty()) printf("%d step(s): worst logits NMSE %.3e, worst max|d|/max|ref| %.3e (bound 1e-3)\n", step_no, worst_nmse, worst_rel);
 
     if (bench > 0) {
+        double ph[5] = { 0, 0, 0, 0, 0 };                       // build, allocate, inputs, graph_compute call, synchronize + one logit back
         auto time_tokens = [&](Runner & R, int n) {
-            const auto t0 = std::chrono::steady_clock::now();
+            using clk = std::chrono::steady_clock;
+            auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            const auto t0 = clk::now();
             int np = n_past;
+            for (int i = 0; i < 5; ++i) ph[i] = 0;
             for (int t = 0; t < n; ++t) {
+                const auto a = clk::now();
                 Step S = build_step(d, R.M, np, 1);
+                const auto b = clk::now();
                 R.alloc(S);
+                const auto c = clk::now();
                 set_inputs(R, S, { next_token() }, np);
+                const auto e = clk::now();
                 R.compute(S);
+                const auto f = clk::now();
                 if (R.sched) ggml_backend_sched_synchronize(R.sched); else ggml_backend_synchronize(R.backends[0]);
                 float l0; ggml_backend_tensor_get(S.logits, &l0, 0, 4);
+                const auto g = clk::now();
+                ph[0] += us(a, b); ph[1] += us(b, c); ph[2] += us(c, e); ph[3] += us(e, f); ph[4] += us(f, g);
                 ggml_free(S.ctx);
                 ++np;
             }
-            return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+            for (int i = 0; i < 5; ++i) ph[i] /= n;
+            return us(t0, clk::now()) / n;
         };
         time_tokens(dev, 3);
         const double us_dev = time_tokens(dev, bench);
+        const double dev_ph[5] = { ph[0], ph[1], ph[2], ph[3], ph[4] };
         double us_cpu = 0; int n_cpu = 0;
         if (run_cpu) { n_cpu = bench < 8 ? bench : 8; us_cpu = time_tokens(cpu, n_cpu); }
         printf("decode through ggml_backend_%s (n_layer %d, n_embd %d, n_ff %d, n_vocab %d, n_past ~%d, graph build + inputs + compute + sync per token): %s %.1f us/token = %.1f tok/s",
                dev.sched ? "sched_graph_compute" : "graph_compute", d.n_layer, d.n_embd, d.n_ff, d.n_vocab, n_past, devs.c_str(), us_dev, 1e6 / us_dev);
         if (n_cpu) printf("; CPU backend %.1f us/token = %.2f tok/s (%d tokens)", us_cpu, 1e6 / us_cpu, n_cpu);
         printf("\n");
+        printf("  host phases per token on the device run: graph build %.1f us, allocation %.1f us, inputs %.1f us, graph_compute call %.1f us, synchronize + logit %.1f us\n",
+               dev_ph[0], dev_ph[1], dev_ph[2], dev_ph[3], dev_ph[4]);
     }
     if (pp > 0 && !dump_only) {
         auto time_prompt = [&](Runner & R, int reps) {
