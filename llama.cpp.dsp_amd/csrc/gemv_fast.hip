@@ -264,8 +264,9 @@ static int launch_one(const GemvArgs & a, dim3 grid, size_t lds_bytes, hipStream
 template <int FAM, int WT, bool EVEN>
 static int launch_cols(const GemvArgs & a, int ncols, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     switch (ncols) {
-    case 1: return launch_one<FAM, WT, 1, 8, EVEN>(a, grid, lds_bytes, stream);
-    case 2: return launch_one<FAM, WT, 2, 6, EVEN>(a, grid, lds_bytes, stream);
+    // (a Q5_K ring slot is 12 registers -- quants, qh bytes, header: 8 of them in flight spill inside the streaming loop, 1.9 TB/s)
+    case 1: return launch_one<FAM, WT, 1, WT == MI355Q_TYPE_Q5_K ? 6 : 8, EVEN>(a, grid, lds_bytes, stream);
+    case 2: return launch_one<FAM, WT, 2, WT == MI355Q_TYPE_Q5_K ? 4 : 6, EVEN>(a, grid, lds_bytes, stream);
     case 3: return launch_one<FAM, WT, 3, 3, EVEN>(a, grid, lds_bytes, stream);
     case 4: return launch_one<FAM, WT, 4, 3, EVEN>(a, grid, lds_bytes, stream);
     case 5: return launch_one<FAM, WT, 5, 2, EVEN>(a, grid, lds_bytes, stream);
