@@ -110,28 +110,33 @@ __global__ void __launch_bounds__(256) k_moe_gather(const char * __restrict__ x,
     float4 * dst = (float4 *) (xg + (int64_t) blockIdx.x * k);
     for (int64_t i = threadIdx.x; i < k / 4; i += 256) dst[i] = src[i];
 }
-// y[p][:] = yg[slot_of_pair[p]][:]; a pair whose expert id is out of range gets NaN (the reference asserts on it; a device kernel cannot)
-__global__ void __launch_bounds__(256) k_moe_scatter(const float * __restrict__ yg, const int32_t * __restrict__ slot_of_pair, float * __restrict__ y, int64_t m) {
-    const int slot = slot_of_pair[blockIdx.x];
+// The matrix-core kernels store every result row straight into y[pair] (MoeTiles::dst_row = order).  What is left for a pass of its own: a pair
+// whose expert id is out of range was given no slot -- its row becomes NaN (the reference asserts on such ids; a device kernel cannot)
+__global__ void __launch_bounds__(256) k_moe_nan_rows(const int32_t * __restrict__ slot_of_pair, float * __restrict__ y, int64_t m) {
+    if (slot_of_pair[blockIdx.x] >= 0) return;
     float * dst = y + (int64_t) blockIdx.x * m;
-    if (slot < 0) { for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = __int_as_float(0x7FC00000); return; }
-    const float * src = yg + (int64_t) slot * m;
-    for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = src[i];
+    for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = __int_as_float(0x7FC00000);
 }
 constexpr int64_t MOE_GROUPED_MIN_PAIRS = 17;      // below: one GEMV column per pair with the ids read on the device
-static int moe_tile(int64_t pairs, int64_t n_expert) {
+// Token tile the expert segments are aligned to.  The integer tiers (Q4_K, Q8_0) run 64-token tiles at full speed.  The bf16 tier dequantizes
+// its weight tile once per workgroup, so there a workgroup covers 128 tokens of one expert and the waves whose 64-token half lies past the
+// segment's end skip their MFMAs: a half-empty tile costs the dequantization it would have cost anyway, not the matrix work.
+static int moe_tile(int type, int64_t k, int64_t pairs, int64_t n_expert) {
     static const int forced = getenv("MI355Q_MOE_TILE") ? atoi(getenv("MI355Q_MOE_TILE")) : 0;      // dev: 64 / 128
+    (void) pairs; (void) n_expert;
     if (forced == 64 || forced == 128) return forced;
-    return pairs / (n_expert > 0 ? n_expert : 1) >= 192 ? 128 : 64;
+    static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr, no_q80 = getenv("MI355Q_NO_MMQ_Q80") != nullptr;
+    const bool integer_tier = (!no_i8 && mmq_i8_supported(type, k)) || (!no_q80 && mmq_q80_supported(type, k));
+    return integer_tier ? 64 : 128;
 }
-static int64_t moe_slots(int64_t pairs, int64_t n_expert) {     // gathered rows incl. the alignment padding of every segment, a multiple of 128
-    const int tile = moe_tile(pairs, n_expert);
+static int64_t moe_slots(int type, int64_t k, int64_t pairs, int64_t n_expert) {     // gathered rows incl. the alignment padding of every segment, a multiple of 128
+    const int tile = moe_tile(type, k, pairs, n_expert);
     return (pairs + n_expert * (tile - 1) + 127) / 128 * 128;
 }
 static size_t moe_grouped_workspace(int type, int64_t m, int64_t k, int64_t pairs, int64_t n_expert) {
-    // [order: slots][slot_of_pair: pairs][seg_end: E][tile_expert: slots / 64] i32 | xg: slots x k f32 | yg: slots x m f32 | scratch of the prefill tier
-    const int64_t slots = moe_slots(pairs, n_expert);
-    return (size_t) (moe_align256(4 * (slots + pairs + n_expert + slots / 64)) + moe_align256(4 * slots * k) + moe_align256(4 * slots * m)) + mi355q_mul_mat_workspace(type, m, slots, k);
+    // [order: slots][slot_of_pair: pairs][seg_end: E][tile_expert: slots / 64] i32 | xg: slots x k f32 | scratch of the prefill tier
+    const int64_t slots = moe_slots(type, k, pairs, n_expert);
+    return (size_t) (moe_align256(4 * (slots + pairs + n_expert + slots / 64)) + moe_align256(4 * slots * k)) + mi355q_mul_mat_workspace(type, m, slots, k);
 }
 static bool moe_grouped_ok(int type, int64_t m, int64_t k, const void * x, int64_t x_stride1, int64_t x_stride2) {
     return mmq_supported(type, k) && m % 4 == 0 && k % 4 == 0 && !(((uintptr_t) x | (uintptr_t) x_stride1 | (uintptr_t) x_stride2) & 15);
@@ -416,35 +421,34 @@ int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert
     if (pairs == 0 || m == 0) return MI355Q_OK;
     if (pairs > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat_id: more than 65535 (token,slot) pairs per call");
     hipStream_t st = (hipStream_t) stream;
-    if (pairs >= MOE_GROUPED_MIN_PAIRS && is_planar(t, k) && n_expert <= 1024 && moe_grouped_ok(type, m, k, x, x_stride1, x_stride2) &&
+    if (pairs >= MOE_GROUPED_MIN_PAIRS && is_planar(t, k) && n_expert <= 1024 && moe_grouped_ok(type, m, k, x, x_stride1, x_stride2) && !((uintptr_t) y & 15) &&
         !(((uintptr_t) w | (uintptr_t) w_stride | (uintptr_t) expert_stride) & 15)) {
         // Prefill-sized batches: rows grouped by expert ON THE DEVICE, one launch of the matrix-core tier over all experts (see k_moe_sort)
         const size_t need = moe_grouped_workspace(type, m, k, pairs, n_expert);
         if (!workspace || workspace_bytes < need) return fail(MI355Q_ERR_WORKSPACE, "mul_mat_id: workspace %zu < %zu for the grouped form", workspace_bytes, need);
-        const int tile = moe_tile(pairs, n_expert);
-        const int64_t slots = moe_slots(pairs, n_expert);
+        const int tile = moe_tile(type, k, pairs, n_expert);
+        const int64_t slots = moe_slots(type, k, pairs, n_expert);
         char * wsp = (char *) workspace;
         int32_t * d_order = (int32_t *) wsp, * d_slot = d_order + slots, * d_seg_end = d_slot + pairs, * d_tile = d_seg_end + n_expert;
         wsp += moe_align256(4 * (slots + pairs + n_expert + slots / 64));
         float * xg = (float *) wsp;                           wsp += moe_align256(4 * slots * k);
-        float * yg = (float *) wsp;                           wsp += moe_align256(4 * slots * m);
         const size_t ws_left = workspace_bytes - (size_t) (wsp - (char *) workspace);
         hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(1024), (size_t) (2 * n_expert * 4), st, (const char *) ids, ids_stride, (int) n_used, (int) pairs, (int) n_expert, tile, (int) slots,
                            d_order, d_slot, d_seg_end, d_tile);
         hipLaunchKernelGGL(k_moe_gather, dim3((unsigned) slots), dim3(256), 0, st, (const char *) x, x_stride1, x_stride2, (int) n_used, (int) x_ne1, d_order, xg, k);
-        const MoeTiles mt = { d_tile, d_seg_end, expert_stride, tile, 0 };
+        const MoeTiles mt = { d_tile, d_seg_end, expert_stride, tile, 0, d_order };
         static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
         static const bool no_q80g = getenv("MI355Q_NO_MMQ_Q80") != nullptr;
         if (!no_i8 && mmq_i8_supported(type, k)) {
-            const mi355q_mat one = { type, w, w_stride, yg, 4 * m, m };
+            const mi355q_mat one = { type, w, w_stride, y, 4 * m, m };
             MQ_TRY(launch_mmq_i8_multi(&one, 1, xg, 4 * k, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
         } else if (!no_q80g && mmq_q80_supported(type, k)) {
-            const mi355q_mat one = { type, w, w_stride, yg, 4 * m, m };
+            const mi355q_mat one = { type, w, w_stride, y, 4 * m, m };
             MQ_TRY(launch_mmq_q80_multi(&one, 1, xg, 4 * k, slots, k, wsp, ws_left, cu_count(), st, true, (flags & MI355Q_FLAG_ROUND_EVEN) != 0, &mt));
         } else {
-            MQ_TRY(launch_mmq_bf16(type, w, w_stride, xg, 4 * k, yg, 4 * m, m, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
+            MQ_TRY(launch_mmq_bf16(type, w, w_stride, xg, 4 * k, y, 4 * m, m, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
         }
-        hipLaunchKernelGGL(k_moe_scatter, dim3((unsigned) pairs), dim3(256), 0, st, yg, d_slot, y, m);
+        hipLaunchKernelGGL(k_moe_nan_rows, dim3((unsigned) pairs), dim3(256), 0, st, d_slot, y, m);
         return hipGetLastError() == hipSuccess ? MI355Q_OK : fail(MI355Q_ERR_HIP, "mul_mat_id: grouped launch failed");
     }
     if (is_planar(t, k) && gemv_fast_family(type) >= 0) {

@@ -82,7 +82,10 @@ inline bool is_planar(const TypeInfo * ti, int64_t k) {   // host only
 // multiples of the token-tile size; token tile t of the gathered rows belongs to expert tile_expert[t] (-1: padding beyond the last segment).
 // A tile's workgroup takes the expert's matrix (w + e * expert_stride) and stores only the rows below seg_end[e].  tile_expert == nullptr:
 // an ordinary dense matmul.
-struct MoeTiles { const int32_t * tile_expert; const int32_t * seg_end; int64_t expert_stride; int tile_tokens; int pad; };
+struct MoeTiles {
+    const int32_t* tile_expert; const int32_t* seg_end; int64_t expert_stride; int tile_tokens; int pad;
+    const int32_t* dst_row;      // slot -> row of y the result belongs to (-1: padding); nullptr: rows are stored in slot order
+};
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers

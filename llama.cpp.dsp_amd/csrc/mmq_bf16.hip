@@ -267,6 +267,8 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
         // ---- prefetch step ks+1 while the matrix cores work on step ks (the last step re-reads itself: no branch) ----
         fetch(step_lo + (ks + 1 < steps ? ks + 1 : ks));
         // ---- 4 k-slices of 32: A = W rows (lane: row l&15, k 8*(l>>4)..+7), B = tokens (lane: col l&15, same k) ----
+        // (grouped launches: a wave whose token half lies past the end of the expert's segment has helped to stage the tile and skips the MFMAs)
+        if (n0 + WN * wn < n)
 #pragma unroll
         for (int kk = 0; kk < MMQ_BK / 32; ++kk) {
             bf16x8 af[MT], bfr[NT];
@@ -288,7 +290,9 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
     for (int j = 0; j < NT; ++j) {
         const int tok = n0 + WN * wn + 16 * j + (lane & 15);
         if (tok >= n) continue;
-        float * yr = (float *) ((char *) y + (int64_t) tok * y_stride);
+        const int dr = moe.dst_row ? moe.dst_row[tok] : tok;                  // grouped MUL_MAT_ID: straight to the pair's row of the result
+        if (dr < 0) continue;
+        float * yr = (float *) ((char *) y + (int64_t) dr * y_stride);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mr = m0 + WM * wm + 16 * i + 4 * (lane >> 4);

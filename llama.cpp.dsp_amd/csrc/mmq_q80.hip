@@ -171,15 +171,17 @@ k_mmq_q80(const Q80Mats mats, const uint8_t * __restrict__ xq, const uint8_t * _
     for (int rt = 0; rt < RT; ++rt) {
         const int row = m0 + 16 * rt + l16;
         if (row >= m) continue;
-        char * yp = (char *) y + (int64_t) (n0 + 4 * kq) * y_stride + 4 * (int64_t) row;
+        char * ycol = (char *) y + 4 * (int64_t) row;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (n0 + 16 * t + 4 * kq + r < n) *(float *) yp = r < 2 ? facc[rt][t].lo[r & 1] : facc[rt][t].hi[r & 1];
-                yp += y_stride;
+                const int tok = n0 + 16 * t + 4 * kq + r;
+                if (tok < n) {
+                    const int dr = moe.dst_row ? moe.dst_row[tok] : tok;      // grouped MUL_MAT_ID: straight to the pair's row of the result
+                    if (dr >= 0) *(float *) (ycol + (int64_t) dr * y_stride) = r < 2 ? facc[rt][t].lo[r & 1] : facc[rt][t].hi[r & 1];
+                }
             }
-            yp += 12 * y_stride;
         }
     }
 }
