@@ -208,6 +208,76 @@ __global__ void __launch_bounds__(256) k_cpy(const TensorD a, TensorD d, int64_t
     }
 }
 
+// Batch-sized copies (the head merge after attention, the K / V stores of a prompt) take one of two forms of the same element-wise copy:
+//  * rows: identical shapes, unit stride along dim 0 on both sides -- 4 elements per thread, 16-byte loads / stores where the addresses allow;
+//  * transpose: a 2-D source that is contiguous along its dim 1 into a destination that is contiguous along its dim 0 (the transposed V cache
+//    store): 64 x 64 tiles through LDS so that both the reads and the writes are whole lines.
+// The values are the same conversions as k_cpy's (f32 -> f16 round to nearest even); only the access pattern differs.
+__global__ void __launch_bounds__(256) k_cpy_rows4(const TensorD a, TensorD d, int64_t n4, char * const * dest_table, int dest_index) {
+    if (dest_table) d.data = dest_table[dest_index];
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t) gridDim.x * blockDim.x) {
+        // logical element e .. e+3: inside one row of the source AND of the destination (both row lengths are multiples of 4; the shapes may differ,
+        // e.g. [head_dim, n_head, n_tokens] -> [n_embd, n_tokens])
+        const int64_t e = 4 * i;
+        const int64_t a0 = e % a.ne[0], ar = e / a.ne[0], a1 = ar % a.ne[1], ar2 = ar / a.ne[1], a2 = ar2 % a.ne[2], a3 = ar2 / a.ne[2];
+        const int64_t d0 = e % d.ne[0], dr = e / d.ne[0], d1 = dr % d.ne[1], dr2 = dr / d.ne[1], d2 = dr2 % d.ne[2], d3 = dr2 / d.ne[2];
+        const char * src = a.data + a0 * a.nb[0] + a1 * a.nb[1] + a2 * a.nb[2] + a3 * a.nb[3];
+        char * dst = d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3];
+        float v[4];
+        if (a.type == 0) {
+            if (((uintptr_t) src & 15) == 0) { const float4 t = *(const float4 *) src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+            else { for (int j = 0; j < 4; ++j) v[j] = ((const float *) src)[j]; }
+        } else {
+            for (int j = 0; j < 4; ++j) v[j] = __half2float(((const __half *) src)[j]);
+        }
+        if (d.type == 0) {
+            if (((uintptr_t) dst & 15) == 0) *(float4 *) dst = make_float4(v[0], v[1], v[2], v[3]);
+            else { for (int j = 0; j < 4; ++j) ((float *) dst)[j] = v[j]; }
+        } else {
+            __half h[4];
+            if (a.type == 1) { for (int j = 0; j < 4; ++j) h[j] = ((const __half *) src)[j]; }
+            else             { for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(v[j]); }
+            if (((uintptr_t) dst & 7) == 0) *(uint2 *) dst = *(const uint2 *) h;
+            else { for (int j = 0; j < 4; ++j) ((__half *) dst)[j] = h[j]; }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_cpy_transpose(const TensorD a, TensorD d, char * const * dest_table, int dest_index) {
+    if (dest_table) d.data = dest_table[dest_index];
+    __shared__ float tile[32][33];                              // 32 x 32 tiles: a 512 x 1024 V store is 512 workgroups, not 128
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t b0 = (int64_t) blockIdx.x * 32, b1 = (int64_t) blockIdx.y * 32, i2 = blockIdx.z % a.ne[2], i3 = blockIdx.z / a.ne[2];
+    const char * ab = a.data + i2 * a.nb[2] + i3 * a.nb[3];
+    char * db = d.data + i2 * d.nb[2] + i3 * d.nb[3];
+    for (int j = ty; j < 32; j += 8) {                           // read: lanes run along the source's contiguous dim 1
+        const int64_t i0 = b0 + j, i1 = b1 + tx;
+        if (i0 < a.ne[0] && i1 < a.ne[1]) tile[j][tx] = ld_elem(ab + i0 * a.nb[0] + i1 * a.nb[1], a.type);
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {                           // write: lanes run along the destination's contiguous dim 0
+        const int64_t i0 = b0 + tx, i1 = b1 + j;
+        if (i0 < a.ne[0] && i1 < a.ne[1]) st_elem(db + i0 * d.nb[0] + i1 * d.nb[1], d.type, tile[tx][j]);
+    }
+}
+static int grid_for(int64_t n);
+static bool cpy_same_shape(const mi355q_tensor * a, const mi355q_tensor * d) { return a->ne[0] == d->ne[0] && a->ne[1] == d->ne[1] && a->ne[2] == d->ne[2] && a->ne[3] == d->ne[3]; }
+// picks the form; returns false when the generic element-wise kernel has to run
+static bool cpy_fast(const mi355q_tensor * a, const mi355q_tensor * d, char * const * table, int index, hipStream_t st) {
+    const int64_t n = nelements(d);
+    if (n < 16384) return false;
+    const int64_t ea = a->type == 0 ? 4 : 2, ed = d->type == 0 ? 4 : 2;
+    if (a->nb[0] == ea && d->nb[0] == ed && a->ne[0] % 4 == 0 && d->ne[0] % 4 == 0) {
+        hipLaunchKernelGGL(k_cpy_rows4, dim3(grid_for(n / 4)), dim3(256), 0, st, to_d(a), to_d(d), n / 4, table, index);
+        return true;
+    }
+    if (cpy_same_shape(a, d) && a->nb[1] == ea && d->nb[0] == ed && a->ne[2] * a->ne[3] <= 65535 && (a->ne[1] + 31) / 32 <= 65535) {
+        hipLaunchKernelGGL(k_cpy_transpose, dim3((unsigned) ((a->ne[0] + 31) / 32), (unsigned) ((a->ne[1] + 31) / 32), (unsigned) (a->ne[2] * a->ne[3])), dim3(256), 0, st,
+                           to_d(a), to_d(d), table, index);
+        return true;
+    }
+    return false;
+}
+
 // ---- SOFT_MAX: one wave per row; mask (f32/f16) broadcast over rows i1 % ne01; ALiBi slope per head -------------
 __global__ void __launch_bounds__(256) k_soft_max(const TensorD a, const TensorD m, const TensorD d, float scale, float max_bias,
                                                   float m0, float m1, uint32_t n_head_log2, int64_t nrows, int has_mask) {
@@ -315,6 +385,47 @@ __global__ void __launch_bounds__(256) k_rope(const TensorD a, const int32_t * p
         const float x0 = ((const float *) src)[e0], x1 = ((const float *) src)[e1];
         ((float *) dst)[e0] = x0 * c - x1 * sn;
         ((float *) dst)[e1] = x0 * sn + x1 * c;
+    }
+}
+
+// Batches: one wave per (token, group of HG heads); lane l owns pairs l, l + 64, ... and computes a pair's angle ONCE for all heads of
+// its group (the CPU fills a per-position cache for the same reason, ggml_rope_cache_init) -- the per-pair operations are those of k_rope,
+// so the results are bit-identical; what changes is 1 / HG of the sincos + theta-chain work and rows read as whole 8-byte-per-lane lines.
+__global__ void __launch_bounds__(256) k_rope_rows(const TensorD a, const int32_t * pos, const float * freq_factors, const TensorD d, const RopeP p, int hg, int64_t n_waves) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const int64_t groups = (a.ne[1] + hg - 1) / hg, g = w % groups, t = w / groups, i2 = t % a.ne[2], i3 = t / a.ne[2];
+    const int64_t h0 = g * hg, h1 = h0 + hg < a.ne[1] ? h0 + hg : a.ne[1];
+    const int64_t half = a.ne[0] / 2;
+    const float fpos = (float) pos[i2];
+    for (int64_t ip = lane; ip < half; ip += 64) {
+        const int64_t i0 = 2 * ip;
+        float c = 1.0f, sn = 0.0f;
+        const bool rot = i0 < p.n_dims;
+        if (rot) {
+            const float ff = freq_factors ? freq_factors[ip] : 1.0f;
+            float th = fpos;
+            for (int64_t j = 0; j < ip; ++j) th = __fmul_rn(th, p.theta_scale);
+            const float theta_extrap = __fdiv_rn(th, ff);
+            const float theta_interp = p.freq_scale * theta_extrap;
+            float theta = theta_interp, mscale = p.attn_factor;
+            if (p.ext_factor != 0.0f) {
+                const float y = ((float) (i0 / 2) - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
+                const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * p.ext_factor;
+                theta = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+                mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+            }
+            c = cosf(theta) * mscale; sn = sinf(theta) * mscale;
+        }
+        const int64_t e0 = (p.neox && rot) ? ip : i0, e1 = (p.neox && rot) ? ip + p.n_dims / 2 : i0 + 1;
+        for (int64_t i1 = h0; i1 < h1; ++i1) {
+            const float * src = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+            float * dst = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+            const float x0 = src[e0], x1 = src[e1];
+            if (rot) { dst[e0] = x0 * c - x1 * sn; dst[e1] = x0 * sn + x1 * c; }
+            else     { dst[e0] = x0; dst[e1] = x1; }
+        }
     }
 }
 
@@ -714,7 +825,8 @@ int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * str
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 / f16 only");
     const int64_t n = nelements(dst);
     if (n == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n, (char * const *) nullptr, 0);
+    if (!cpy_fast(a, dst, nullptr, 0, (hipStream_t) stream))
+        hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n, (char * const *) nullptr, 0);
     OPS_LAUNCHED();
 }
 
@@ -723,7 +835,8 @@ int mi355q_op_cpy_indirect(const mi355q_tensor * a, const mi355q_tensor * dst, v
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 / f16 only");
     const int64_t n = nelements(dst);
     if (n == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n, (char * const *) dest_table, index);
+    if (!cpy_fast(a, dst, (char * const *) dest_table, index, (hipStream_t) stream))
+        hipLaunchKernelGGL(k_cpy, dim3(grid_for(n)), dim3(256), 0, (hipStream_t) stream, to_d(a), to_d(dst), n, (char * const *) dest_table, index);
     OPS_LAUNCHED();
 }
 
@@ -837,7 +950,14 @@ int mi355q_op_rope(const mi355q_tensor * a, const int32_t * pos, const float * f
     auto corr_dim = [&](float n_rot) { return p->n_dims * logf(p->n_ctx_orig / (n_rot * 2 * 3.14159265358979323846f)) / (2 * logf(p->freq_base)); };
     const float start = floorf(corr_dim(p->beta_fast)), end = ceilf(corr_dim(p->beta_slow));
     rp.corr0 = start > 0 ? start : 0; rp.corr1 = end < p->n_dims - 1 ? end : (float) (p->n_dims - 1);
-    hipLaunchKernelGGL(k_rope, dim3(grid_for(n_pairs)), dim3(256), 0, (hipStream_t) stream, to_d(a), pos, freq_factors, to_d(dst), rp, n_pairs);
+    const int64_t tokens = a->ne[2] * a->ne[3];
+    if (tokens >= 32 && a->ne[1] >= 2) {                        // a batch: the angle of a (position, pair) is shared by a group of heads
+        int hg = 1;
+        while (hg < 8 && 2 * hg <= a->ne[1] && tokens * ((a->ne[1] + 2 * hg - 1) / (2 * hg)) >= 2048) hg *= 2;
+        const int64_t n_waves = tokens * ((a->ne[1] + hg - 1) / hg);
+        hipLaunchKernelGGL(k_rope_rows, dim3((unsigned) ((n_waves + 3) / 4)), dim3(256), 0, (hipStream_t) stream, to_d(a), pos, freq_factors, to_d(dst), rp, hg, n_waves);
+    } else
+        hipLaunchKernelGGL(k_rope, dim3(grid_for(n_pairs)), dim3(256), 0, (hipStream_t) stream, to_d(a), pos, freq_factors, to_d(dst), rp, n_pairs);
     OPS_LAUNCHED();
 }
 

@@ -78,6 +78,44 @@ def test_unary_and_cpy(G, torch):
     assert np.array_equal(out.cpu().numpy(), k.transpose(0, 1, 3, 2))
 
 
+def test_cpy_batch_forms(G, torch):
+    """Copies of >= 16384 elements with identical shapes take the row form (unit stride along dim 0 on both sides) or the tiled-transpose form
+    (source contiguous along dim 1, destination along dim 0): same values as the element-wise kernel, i.e. exactly numpy's."""
+    rng = np.random.default_rng(31)
+    nt, nh, hd, n_ctx = 200, 32, 128, 512
+    # (1) the head merge after attention: CONT of KQV [hd, n_tokens, n_head] viewed as [hd, n_head, n_tokens]
+    kqv = rng.standard_normal((1, nh, nt, hd)).astype(np.float32)
+    out = torch.empty((1, nt, nh, hd), dtype=torch.float32, device="cuda")
+    G.op_cpy(dev(torch, kqv).permute(0, 2, 1, 3), out)
+    assert np.array_equal(out.cpu().numpy(), kqv.transpose(0, 2, 1, 3))
+    out2 = torch.empty((1, 1, nt, nh * hd), dtype=torch.float32, device="cuda")            # ggml_cont_2d: another shape, same elements
+    G.op_cpy(dev(torch, kqv).permute(0, 2, 1, 3), out2)
+    assert np.array_equal(out2.cpu().numpy().reshape(1, nt, nh, hd), kqv.transpose(0, 2, 1, 3))
+    # (2) K store of a prompt: f32 rows -> f16 cache rows with a larger pitch, at an offset that is only 8-byte aligned
+    k = rng.standard_normal((1, 1, nt, 1024)).astype(np.float32)
+    cache = torch.zeros((1, 1, nt, 2048 + 4), dtype=torch.float16, device="cuda")
+    G.op_cpy(dev(torch, k), cache[..., 4:1028])
+    assert np.array_equal(cache[..., 4:1028].cpu().numpy(), k.astype(np.float16)) and float(cache[..., :4].abs().max()) == 0.0 and float(cache[..., 1028:].abs().max()) == 0.0
+    back = torch.empty((1, 1, nt, 1024), dtype=torch.float32, device="cuda")
+    G.op_cpy(cache[..., 4:1028], back)                        # f16 -> f32 rows
+    assert np.array_equal(back.cpu().numpy(), k.astype(np.float16).astype(np.float32))
+    h2 = torch.empty((1, 1, nt, 1024), dtype=torch.float16, device="cuda")
+    G.op_cpy(cache[..., 4:1028], h2)                          # f16 -> f16 rows
+    assert np.array_equal(h2.cpu().numpy(), k.astype(np.float16))
+    # (3) the transposed V store: v [n_embd_v, n_tokens] seen transposed -> cache view [n_tokens (contiguous), n_embd_v (pitch n_ctx)], f32 -> f16,
+    #     ragged against the 64 x 64 tiles
+    v = rng.standard_normal((1, 1, nt, 1000)).astype(np.float32)                     # [n_tokens][n_embd_v] in memory
+    vcache = torch.zeros((1, 1, 1000, n_ctx), dtype=torch.float16, device="cuda")
+    G.op_cpy(dev(torch, v).permute(0, 1, 3, 2), vcache[..., 7:7 + nt])
+    assert np.array_equal(vcache[..., 7:7 + nt].cpu().numpy(), v.transpose(0, 1, 3, 2).astype(np.float16))
+    assert float(vcache[..., :7].abs().max()) == 0.0 and float(vcache[..., 7 + nt:].abs().max()) == 0.0
+    # (4) a transposed f32 -> f32 copy with batch dims
+    m = rng.standard_normal((2, 3, 70, 130)).astype(np.float32)
+    o = torch.empty((2, 3, 130, 70), dtype=torch.float32, device="cuda")
+    G.op_cpy(dev(torch, m).permute(0, 1, 3, 2), o)
+    assert np.array_equal(o.cpu().numpy(), m.transpose(0, 1, 3, 2))
+
+
 def test_soft_max(G, torch):
     rng = np.random.default_rng(4)
     kq = (rng.standard_normal((1, 32, 3, 513)) * 3).astype(np.float32)
@@ -103,6 +141,28 @@ def test_rope(G, torch):
             assert np.abs(y - ref).max() <= 6e-5 * np.abs(ref).max(), (mode, n_dims, fscale, ext)
     with pytest.raises(G.Mi355qError):
         G.op_rope(dev(torch, x), dev(torch, pos), 128, 8)                                            # mrope: not on the device
+
+
+def test_rope_batch_kernel_bit_identical(G, torch):
+    """Batches of >= 32 tokens take the kernel that computes a (position, pair) angle once per group of heads (k_rope_rows): the per-pair
+    operations are those of the one-thread-per-pair kernel, so the two must agree bit for bit -- here against the same rows roped in slices of
+    8 tokens (which take the per-pair kernel), in both modes, with partial rotation, frequency factors, YaRN, and a head count that is not a
+    multiple of the group size."""
+    rng = np.random.default_rng(55)
+    ff = rng.uniform(1.0, 8.0, 64).astype(np.float32)
+    for nt, nh in ((512, 32), (40, 7), (64, 8)):
+        x = rng.standard_normal((1, nt, nh, 128)).astype(np.float32)
+        pos = rng.integers(0, 8192, nt).astype(np.int32)
+        for mode in (0, 2):
+            for n_dims, freq, fscale, ext in ((128, None, 1.0, 0.0), (64, ff, 1.0, 0.0), (128, None, 0.25, 1.0)):
+                fq = dev(torch, freq[:n_dims // 2]) if freq is not None else None
+                args = (n_dims, mode, fq, 8192, 500000.0, fscale, ext, 1.0, 32.0, 1.0)
+                y = G.op_rope(dev(torch, x), dev(torch, pos), *args).cpu().numpy()
+                parts = [G.op_rope(dev(torch, x[:, t0:t0 + 8]), dev(torch, pos[t0:t0 + 8]), *args).cpu().numpy() for t0 in range(0, nt, 8)]
+                assert np.array_equal(y.view(np.uint32), np.concatenate(parts, axis=1).view(np.uint32)), (nt, nh, mode, n_dims)
+        ref = glue.rope(x, pos, 128, 0, None, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+        y = G.op_rope(dev(torch, x), dev(torch, pos), 128, 0, None, 8192, 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0).cpu().numpy()
+        assert np.abs(y - ref).max() <= 6e-5 * np.abs(ref).max()
 
 
 def test_mul_mat_f_attention_shapes(G, torch):
