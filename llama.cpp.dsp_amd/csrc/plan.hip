@@ -434,6 +434,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
         }
         plan_lds_barrier();
         if (!c.ctl[CTL_OK]) return false;
+        PLAN_STAMP(6);
         float scale = 1.0f;
         if (x_kind == MI355Q_X_NORM) {
             double s = 0.0;
@@ -457,6 +458,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
             }
             plan_quantize_span<FAM>(v, span, c.lds, k, c.even != 0, lane);
         }
+        PLAN_STAMP(7);
         plan_lds_barrier();
     }
     plan_fill<T, PLAN_D>(ring, st->prime, PLAN_D, ld, sw, g, lane);                // top the ring up (a no-op when prime == depth)

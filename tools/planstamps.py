@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel timeline of the decode plan (diagnostic build libmi355q_dbg.so; dev tool, GPU box only).
-Per stage and workgroup, waves 0 and 15 stamp  GEMV: 0 entry, 5 descriptor fields arrived, 1 primed, 2 operands gathered (producers polled), 3 activations quantized in LDS, 4 rows done;
+Per stage and workgroup, waves 0 and 15 stamp  GEMV: 0 entry, 5 descriptor fields arrived, 1 primed, 2 operands gathered (producers polled), 6 all waves gathered (barrier passed), 7 this wave's spans quantized, 3 activations quantized in LDS (barrier passed), 4 rows done;
 ATTN: 0 entry, 1 q/k/v gathered, 2 roped + stored, 3 scores, 4 softmax, 5 P.V published;  COMBINE: 0 entry, 2 merged.
 Usage: MI355Q_LIB=.../libmi355q_dbg.so python tools/planstamps.py [--layers 2] [--pos 100]"""
 import argparse, ctypes, sys
@@ -38,7 +38,7 @@ s = np.where(s > 0, (s - t0) / 100.0, np.nan)          # us
 print(f"{n} launch stages; times in us since the first stage entry; per stamp: min / median / max over workgroups (wave 0 | median wave 15)")
 for st in range(n):
     line = [f"stage {st:3d}"]
-    for i in (0, 5, 1, 2, 3, 4):
+    for i in (0, 5, 1, 2, 6, 7, 3, 4):
         c0, c1 = s[st, :, 0, i], s[st, :, 1, i]
         if np.all(np.isnan(c0)):
             continue
