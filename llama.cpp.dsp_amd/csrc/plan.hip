@@ -36,7 +36,7 @@ constexpr int PLAN_D_MAX = 8;                     // ring depth (1-KiB steps in 
 __host__ __device__ constexpr int plan_depth(int type) {   // Q5_K / Q6_K slots carry qh too (1.5 KiB per step): 6 steps are the bytes of 8 Q4_K steps
     return (type == MI355Q_TYPE_Q5_K || type == MI355Q_TYPE_Q6_K) ? 6 : PLAN_D_MAX;
 }
-enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32 };
+enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32, PLAN_F_DIRECT = 64 };
 enum { PLAN_K_GEMV = 0, PLAN_K_ATTN = 1, PLAN_K_COMBINE = 2 };
 enum { PLAN_SYNC_ABORT = 0, PLAN_SYNC_WORDS = 32 };
 
@@ -383,6 +383,48 @@ __device__ __forceinline__ void plan_quantize_span(const float4 v, int span, uin
     else                          quantize_span_to_lds<FAM_Q80, false>(v, span, lds, k, lane);
 }
 
+// A stage whose activation vector is ONE vector taken as it is (X_PLAIN, no second operand: wo, ffn_down): a wave fetches whole 256-element
+// spans -- lane l the four elements 4l .. 4l+3, i.e. two 16-byte granule loads -- and quantizes each span into the LDS image straight from its
+// registers.  No staging copy and no workgroup barrier between gathering and quantizing (plan_gather needs one: its chunks are dealt 16 apart,
+// so a 256-block's two halves sit in different waves).  Two spans (four loads) are in flight per poll.  false = the poll gave up.
+template <int FAM>
+__device__ __forceinline__ bool plan_gather_direct(StageC st, const StageCtx & c, int k, int wave, int lane) {
+    VecSrc v0;
+    v0.plain = st->x0.plain; v0.gran = st->x0.gran; v0.tag_off = st->x0.tag_off; v0.pad = 0;
+    const SrcView s0 = src_view(v0, 0, k, c.epoch);
+    const int spans = k >> 8;                                  // (k % 256 == 0, checked at plan creation)
+    PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+#pragma unroll 1
+    for (int sp = wave; sp < spans; sp += 2 * GEMV_WAVES) {
+        const int sp2 = sp + GEMV_WAVES;
+        float4 va, vb;
+        for (;;) {
+            bool ok = true;
+            if (s0.tagged) {
+                const plan_u4 a0 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp * 2048 + 32 * lane, 0, 16 /* sc1 */);
+                const plan_u4 a1 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp * 2048 + 32 * lane + 16, 0, 16);
+                const plan_u4 b0 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp2 * 2048 + 32 * lane, 0, 16);      // (past the vector: zeros, not checked)
+                const plan_u4 b1 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp2 * 2048 + 32 * lane + 16, 0, 16);
+                va = make_float4(__uint_as_float(a0.x), __uint_as_float(a0.z), __uint_as_float(a1.x), __uint_as_float(a1.z));
+                vb = make_float4(__uint_as_float(b0.x), __uint_as_float(b0.z), __uint_as_float(b1.x), __uint_as_float(b1.z));
+                ok = a0.y == s0.expect && a0.w == s0.expect && a1.y == s0.expect && a1.w == s0.expect;
+                if (sp2 < spans) ok = ok && b0.y == s0.expect && b0.w == s0.expect && b1.y == s0.expect && b1.w == s0.expect;
+            } else {
+                const plan_u4 a = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp * 1024 + 16 * lane, 0, 0);
+                const plan_u4 b = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp2 * 1024 + 16 * lane, 0, 0);
+                va = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+                vb = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+            }
+            if (__ballot(!ok) == 0ull) break;
+            if (!poll_backoff(pc, spins, lane)) return false;
+        }
+        plan_quantize_span<FAM>(va, sp, c.lds, k, c.even != 0, lane);
+        if (sp2 < spans) plan_quantize_span<FAM>(vb, sp2, c.lds, k, c.even != 0, lane);
+    }
+    return true;
+}
+
 // One GEMV stage, start to finish, for weight type T:
 //   prime (weights in flight) -> [gather x (polls its producers) -> glue -> quantize x -> LDS] -> stream rows, publishing every y
 template <int T>
@@ -420,6 +462,13 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     if (flags & PLAN_F_NEW_X) {
         constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? FAM_Q80 : FAM_Q8K;
         plan_lds_barrier();                                   // all waves are done with the previous LDS image and staging area
+        if (flags & PLAN_F_DIRECT) {                          // one plain vector: gathered and quantized span by span, one barrier
+            const bool okd = plan_gather_direct<FAM>(st, c, k, wave, lane);
+            if (!okd && lane == 0) c.ctl[CTL_OK] = 0;
+            PLAN_STAMP(2);
+            plan_lds_barrier();
+            if (!c.ctl[CTL_OK]) return false;
+        } else {
         const int x_kind = st->x_kind;
         const float * nw = x_kind == MI355Q_X_NORM ? st->norm_w : nullptr;
         float4 w_first = make_float4(1.f, 1.f, 1.f, 1.f);      // the norm weights of this wave's first span: fetched before the producers are polled
@@ -460,6 +509,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
         }
         PLAN_STAMP(7);
         plan_lds_barrier();
+        }
     }
     plan_fill<T, PLAN_D>(ring, st->prime, PLAN_D, ld, sw, g, lane);                // top the ring up (a no-op when prime == depth)
     sw.load_out(st);
@@ -638,49 +688,39 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in,
     }
     plan_lds_barrier();
     PLAN_STAMP(3);
-    // 4. local softmax statistics
-    float mx = -INFINITY;
-    for (int j = tid; j < cnt; j += GEMV_THREADS) mx = fmaxf(mx, sc[j]);
-    mx = wave_max_f(mx);
-    if (lane == 0) maxs[wave] = mx;
-    plan_lds_barrier();
-    mx = maxs[0];
-#pragma unroll
-    for (int i = 1; i < GEMV_WAVES; ++i) mx = fmaxf(mx, maxs[i]);
-    float l;
-    if (a->p_f16) {
-        // The non-flash graph of the reference (SOFT_MAX, then MUL_MAT(v, kq) whose f16 src0 makes the CPU round kq to f16): the whole window is in
-        // this workgroup, so the probabilities are formed exactly as ggml_compute_forward_soft_max_f32 does -- sum of the exponentials in f64,
-        // p = e * (float) (1 / sum) -- and rounded to f16 before they meet V.  (An f32 P.V is closer to the exact product, but the next matmul
-        // re-quantizes its input and amplifies any 1e-4 difference from the CPU to ~1 % of the logits: DESIGN.md section 3b.)
-        double ds = 0.0;
-        for (int j = tid; j < cnt; j += GEMV_THREADS) {
-            const float e = mx == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx));
-            sc[j] = e; ds += (double) e;
+    // 4. local softmax statistics.  A split holds at most a few hundred scores: ONE wave forms maximum, exponentials, sum and (single split) the
+    //    probabilities with register reductions, the other 15 wait at one barrier -- the workgroup-wide form cost three barriers for the same numbers.
+    if (wave == 0) {
+        float mx0 = -INFINITY;
+        for (int j = lane; j < cnt; j += 64) mx0 = fmaxf(mx0, sc[j]);
+        mx0 = wave_max_f(mx0);
+        float l0;
+        if (a->p_f16) {
+            // The non-flash graph of the reference (SOFT_MAX, then MUL_MAT(v, kq) whose f16 src0 makes the CPU round kq to f16): the whole window is in
+            // this workgroup, so the probabilities are formed exactly as ggml_compute_forward_soft_max_f32 does -- sum of the exponentials in f64,
+            // p = e * (float) (1 / sum) -- and rounded to f16 before they meet V.  (An f32 P.V is closer to the exact product, but the next matmul
+            // re-quantizes its input and amplifies any 1e-4 difference from the CPU to ~1 % of the logits: DESIGN.md section 3b.)
+            double ds = 0.0;
+            for (int j = lane; j < cnt; j += 64) {
+                const float e = mx0 == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx0));
+                sc[j] = e; ds += (double) e;
+            }
+            ds = wave_sum_f64(ds);
+            const float inv = (float) (1.0 / ds);
+            for (int j = lane; j < cnt; j += 64) sc[j] = __half2float(__float2half_rn(__fmul_rn(sc[j], inv)));      // (a lane re-reads only what it wrote)
+            l0 = 1.0f;
+        } else {
+            float ls = 0.0f;
+            for (int j = lane; j < cnt; j += 64) {
+                const float p = mx0 == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx0));
+                sc[j] = p; ls += p;
+            }
+            l0 = wave_sum(ls);
         }
-        ds = wave_sum_f64(ds);
-        if (lane == 0) c.part[wave] = ds;
-        plan_lds_barrier();
-        double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < GEMV_WAVES; ++i) tot += c.part[i];
-        const float inv = (float) (1.0 / tot);
-        for (int j = tid; j < cnt; j += GEMV_THREADS) sc[j] = __half2float(__float2half_rn(__fmul_rn(sc[j], inv)));
-        plan_lds_barrier();
-        l = 1.0f;
-    } else {
-        float ls = 0.0f;
-        for (int j = tid; j < cnt; j += GEMV_THREADS) {
-            const float p = mx == -INFINITY ? 0.0f : expf(__fsub_rn(sc[j], mx));
-            sc[j] = p; ls += p;
-        }
-        ls = wave_sum(ls);
-        if (lane == 0) sums[wave] = ls;
-        plan_lds_barrier();
-        l = 0.0f;
-#pragma unroll
-        for (int i = 0; i < GEMV_WAVES; ++i) l += sums[i];
+        if (lane == 0) { maxs[0] = mx0; sums[0] = l0; }
     }
+    plan_lds_barrier();
+    const float mx = maxs[0], l = sums[0];
     PLAN_STAMP(4);
     // 5. o[d] = sum_j p_j v[j][d]   (positions with p == 0 are skipped: masked cache rows may hold anything)
     const char * vbase = a->v_cache + (int64_t) g * a->v_nb_head;
@@ -1052,6 +1092,10 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 p.flags |= PLAN_F_SUM | ((in.flags & MI355Q_STAGE_NO_PLAIN) ? 0 : PLAN_F_SUM_PLAIN);
                 p.sum_plain = in.sum_out;
                 p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off, in.sum_id) + 1);
+            }
+            {   // one plain vector of whole 256-element spans: the direct gather + quantize form (MI355Q_PLAN_DIRECT=0 turns it off: A/B measurements)
+                static const bool no_direct = getenv("MI355Q_PLAN_DIRECT") && atoi(getenv("MI355Q_PLAN_DIRECT")) == 0;
+                if (first && !no_direct && in.x_kind == MI355Q_X_PLAIN && !in.x1 && in.k % 256 == 0) p.flags |= PLAN_F_DIRECT;
             }
             if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
