@@ -104,14 +104,18 @@ __device__ int g_plan_stamp_stages = 0;
 // scalar loads (one round trip).  Reading them per row instead (matrix index -> base -> stride: a dependent chain of
 // scalar loads) costs microseconds whenever the descriptors miss the scalar cache.
 struct StageW {
-    const uint8_t * w0, * w1, * w2, * w3; int64_t ws0, ws1, ws2, ws3; float * y0, * y1, * y2, * y3; Granule * g; int rb1, rb2, rb3;
+    const uint8_t * w0, * w1, * w2, * w3; int64_t ws0, ws1, ws2, ws3; float * y0, * y1, * y2, * y3; Granule * g; int rb1, rb2, rb3; int paired;
     __device__ __forceinline__ void load(StageC st) {          // what the loader needs (live through the prologue)
+        paired = 0;
         w0 = st->w[0]; w1 = st->w[1]; w2 = st->w[2]; w3 = st->w[3];
         ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = st->w_stride[2]; ws3 = st->w_stride[3];
         rb1 = st->row_begin[1]; rb2 = st->row_begin[2]; rb3 = st->row_begin[3];
     }
-    // PAIRED stage (y = unary(W0 x) * (W1 x)): this workgroup's LOCAL rows [0, np) are rows p0.. of matrix 0, [np, 2 np) the same rows of matrix 1
+    // PAIRED stage (y = unary(W0 x) * (W1 x)): this workgroup's LOCAL row 2 q is row p0 + q of matrix 0, local row 2 q + 1 the same row of matrix 1.
+    // A wave takes pairs q = wave, wave + 16, ... and streams the two rows of a pair back to back (plan_next_row), so it holds both dot products
+    // itself and publishes unary(.) * (.) without a trip through LDS.
     __device__ __forceinline__ void load_paired(StageC st, int p0, int np) {
+        paired = 1;
         ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = ws3 = 0;
         w0 = st->w[0] + (int64_t) p0 * ws0; w1 = st->w[1] + (int64_t) p0 * ws1; w2 = w3 = nullptr;
         rb1 = np; rb2 = rb3 = 0x7FFFFFFF;
@@ -124,6 +128,7 @@ struct StageW {
         const uint64_t a0 = (uint64_t) w0, a1 = (uint64_t) w1, a2 = (uint64_t) w2, a3 = (uint64_t) w3;
         const int64_t s0 = ws0, s1 = ws1, s2 = ws2, s3 = ws3;
         const int b1 = rb1, b2 = rb2, b3 = rb3;
+        if (paired) return (const uint8_t *) (((r & 1) ? a1 : a0) + (uint64_t) ((int64_t) (r >> 1) * ((r & 1) ? s1 : s0)));
         const int mi = (r >= b1) + (r >= b2) + (r >= b3);      // row_begin is ascending
         const uint64_t w = mi == 0 ? a0 : mi == 1 ? a1 : mi == 2 ? a2 : a3;
         const int64_t ws = mi == 0 ? s0 : mi == 1 ? s1 : mi == 2 ? s2 : s3;
@@ -149,11 +154,14 @@ template <int T> __device__ __forceinline__ StageGeom plan_geom(int k, int r_hi)
     return g;
 }
 
+// the row a wave takes after local row r: rows are dealt round robin; a PAIRED stage deals PAIRS (rows 2q, 2q+1 back to back, then 16 pairs on)
+__device__ __forceinline__ int plan_next_row(int r, int paired) { return r + (paired ? ((r & 1) ? 2 * GEMV_WAVES - 1 : 1) : GEMV_WAVES); }
+
 template <int T>
 __device__ __forceinline__ void plan_issue(Chunk & slot, PlanCursor & ld, const StageW & st, const StageGeom & g, int lane) {
     if (ld.gr < g.r_hi) {                                     // wave-uniform
         if (64 * ld.s + lane < g.nchunks) chunk_load<T>(slot, ld.row, g.nb, ld.s, lane);
-        if (++ld.s == g.steps) { ld.s = 0; ld.gr += GEMV_WAVES; if (ld.gr < g.r_hi) ld.row = st.row_ptr(ld.gr); }
+        if (++ld.s == g.steps) { ld.s = 0; ld.gr = plan_next_row(ld.gr, st.paired); if (ld.gr < g.r_hi) ld.row = st.row_ptr(ld.gr); }
     }
 }
 
@@ -168,15 +176,18 @@ __device__ __forceinline__ void publish(Granule * gp, float v, unsigned tag) {
     __hip_atomic_store(gp, ((Granule) tag << 32) | (Granule) __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ float unary_f(int uop, float x);
+
 // consume this wave's rows of the stage; slot d holds item d, d+D, ... ; refills keep D items in flight
 template <int T, int D>
 __device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, const StageW & st, const StageGeom & g, int r_lo, int wave, int lane,
-                                         const ActView * av, unsigned tag, bool plain, float * pair_lds) {
+                                         const ActView * av, unsigned tag, bool plain, int pair_p0, int pair_unary) {
     // the consumers' lane-invariant state (LDS offsets, shifts) is derived from an opaque copy of the lane id HERE, so
     // that it cannot be computed (and kept live, and spilled) before the prologue
     int lane_c = lane; asm volatile("" : "+v"(lane_c));
-    int cs_gr = r_lo + wave, cs_s = 0;
+    int cs_gr = r_lo + (st.paired ? 2 * wave : wave), cs_s = 0;
     float acc[1] = { 0.0f };
+    float first_of_pair = 0.0f;                              // PAIRED: the dot product of the pair's matrix-0 row, until the matrix-1 row is done
     while (cs_gr < g.r_hi) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -184,11 +195,15 @@ __device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, cons
                 if (64 * cs_s + lane_c < g.nchunks) Consume<T, 1>::run(ring[d], cs_s, lane_c, av, acc);
                 if (++cs_s == g.steps) {                      // row finished: reduce, publish (one granule), next row
                     const float t = wave_sum(acc[0]);
-                    if (lane_c == 0) {
-                        if (pair_lds) pair_lds[cs_gr] = t;    // PAIRED stage: the workgroup combines its rows after the loop
-                        else { publish(st.g + cs_gr, t, tag); if (plain) *st.y_ptr(cs_gr) = t; }
-                    }
-                    acc[0] = 0.0f; cs_s = 0; cs_gr += GEMV_WAVES;
+                    if (st.paired) {                           // (wave-uniform)
+                        if (!(cs_gr & 1)) first_of_pair = t;
+                        else if (lane_c == 0) {
+                            const float r = __fmul_rn(unary_f(pair_unary, first_of_pair), t);
+                            publish(st.g + pair_p0 + (cs_gr >> 1), r, tag);
+                            if (plain) st.y0[pair_p0 + (cs_gr >> 1)] = r;
+                        }
+                    } else if (lane_c == 0) { publish(st.g + cs_gr, t, tag); if (plain) *st.y_ptr(cs_gr) = t; }
+                    acc[0] = 0.0f; cs_s = 0; cs_gr = plan_next_row(cs_gr, st.paired);
                 }
                 plan_issue<T>(ring[d], ld, st, g, lane);      // refill the slot just consumed
             }
@@ -449,7 +464,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     constexpr int PLAN_D = plan_depth(T);
     Chunk ring[PLAN_D];
     PlanCursor ld;
-    ld.gr = r_lo + wave; ld.s = 0; ld.row = nullptr;
+    ld.gr = r_lo + (sw.paired ? 2 * wave : wave); ld.s = 0; ld.row = nullptr;
     if (ld.gr < r_hi) ld.row = sw.row_ptr(ld.gr);
 #ifdef MI355Q_STAMPS
     { unsigned long long probe = (unsigned long long) (uintptr_t) ld.row + (unsigned) k; asm volatile("" :: "s"(probe)); }   // (forces the descriptor's scalar loads to have returned)
@@ -516,18 +531,10 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     PLAN_STAMP(3);
     ActView av[1];
     av[0].base = c.lds; av[0].k = k;
-    float * pair_lds = (flags & PLAN_F_PAIRED) ? c.stg : nullptr;      // (the staging area is free once the activations are quantized)
-    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av, c.epoch + st->tag_off, (flags & PLAN_F_PLAIN_Y) != 0, pair_lds);
+    // (a PAIRED stage publishes unary(row of matrix 0) * (row of matrix 1) per pair from the wave that streamed both: the output unary is kept in
+    // the high byte of x_unary)
+    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av, c.epoch + st->tag_off, (flags & PLAN_F_PLAIN_Y) != 0, pair_p0, st->x_unary >> 8);
     PLAN_STAMP(4);
-    if (flags & PLAN_F_PAIRED) {
-        plan_lds_barrier();                                   // every wave's rows are in LDS
-        const int uop = st->x_unary >> 8;                     // (the output unary is kept in the high byte)
-        for (int i = (int) threadIdx.x; i < pair_np; i += GEMV_THREADS) {
-            const float t = __fmul_rn(unary_f(uop, pair_lds[i]), pair_lds[pair_np + i]);
-            publish(sw.g + pair_p0 + i, t, c.epoch + st->tag_off);
-            if (flags & PLAN_F_PLAIN_Y) sw.y0[pair_p0 + i] = t;
-        }
-    }
     return true;
 }
 
@@ -1100,7 +1107,6 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;
-            if (paired && (size_t) (2 * rpw * 4 + 64) > stg_max) stg_max = (size_t) (2 * rpw * 4 + 64);
             p.prime = plan_depth(type);
             v.push_back(p); attn_of.push_back(-1);
             set |= tbit(type);
