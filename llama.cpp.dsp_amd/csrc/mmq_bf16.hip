@@ -191,7 +191,7 @@ template <> struct W32<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]
 // CUs idle or with a single workgroup (one wave per SIMD hides no latency) get smaller tiles: 64 x 64 tiles need 35 KiB
 // of LDS, so four workgroups share a CU.
 template <int T, int MMQ_BM, int MMQ_BN>
-__global__ void __launch_bounds__(MMQ_THREADS, (MMQ_BM == 64 && MMQ_BN == 64) ? 4 : 2)
+__global__ void __launch_bounds__(MMQ_BN == 256 ? 512 : MMQ_THREADS, MMQ_BN == 256 ? 1 : (MMQ_BM == 64 && MMQ_BN == 64) ? 4 : 2)
 k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __restrict__ xb /* bf16 [n][k] */,
            float * __restrict__ y, int64_t y_stride, int m, int n, int k, int n_split, int64_t split_stride /* floats between the partial outputs */,
            const MoeTiles moe) {
@@ -199,9 +199,13 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
     uint8_t * Ws = lds;
     uint8_t * Xs = lds + MMQ_BM * MMQ_LDS_STRIDE;                          // BN rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    constexpr int WM = MMQ_BM / 2, WN = MMQ_BN / 2, MT = WM / 16, NT = WN / 16;
-    constexpr int UW = MMQ_BM * 4 / MMQ_THREADS, UX = MMQ_BN * 4 / MMQ_THREADS;
+    // 128 x 256 tiles run with 8 waves (2 x 4: the same 64 x 64 per wave as the 128 x 128 tile) -- one dequantized weight tile then serves
+    // 256 tokens instead of 128, which is what the dequantization-bound types (Q6_K) pay for
+    constexpr int NTHREADS = MMQ_BN == 256 ? 512 : MMQ_THREADS, WAVES_N = MMQ_BN == 256 ? 4 : 2;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    constexpr int WM = MMQ_BM / 2, WN = MMQ_BN / WAVES_N, MT = WM / 16, NT = WN / 16;
+    constexpr int UW = MMQ_BM * 4 / NTHREADS, UX = MMQ_BN * 4 / NTHREADS;
+    static_assert(UW >= 1 && UW <= 2 && UX >= 1 && UX <= 2, "one or two staging units per thread");
     const int m0 = blockIdx.x * MMQ_BM, n0 = blockIdx.y * MMQ_BN;
     if (moe.tile_expert) {                                    // grouped MUL_MAT_ID: this token tile's expert (uniform per workgroup)
         const int e = moe.tile_expert[n0 / moe.tile_tokens];
@@ -218,7 +222,7 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
 
     // dequant units: (row, quarter) = ((tid + 256 u) >> 2, tid & 3), u < UW; out-of-range rows read row 0 (never stored).
     // (Named variables, not arrays indexed by u: the compiler leaves such small arrays in scratch memory.)
-    const int quarter = tid & 3, r0 = tid >> 2, r1 = (tid + MMQ_THREADS) >> 2;
+    const int quarter = tid & 3, r0 = tid >> 2, r1 = (tid + NTHREADS) >> 2;
     const uint8_t * wrow0 = w + (int64_t) (m0 + r0 < m ? m0 + r0 : 0) * w_stride;
     const uint8_t * wrow1 = w + (int64_t) (m0 + r1 < m ? m0 + r1 : 0) * w_stride;
     const uint16_t * xrow0 = xb + (int64_t) (n0 + r0 < n ? n0 + r0 : 0) * k + 32 * quarter;
@@ -366,6 +370,8 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     // latency at all.
     auto tiles = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
     int bm = 64, bn = 64;                                     // measured on pp512 shapes: 128x128 wins from ~1.5 workgroups per CU on
+    static const int wide_env = getenv("MI355Q_MMQ_BF16_WIDE") ? atoi(getenv("MI355Q_MMQ_BF16_WIDE")) : -1;      // dev: 0 = never, 1 = whenever n >= 256
+    const bool wide_type = type == MI355Q_TYPE_Q6_K || type == MI355Q_TYPE_Q5_K;                                  // (the types whose dequantization dominates)
     if (2 * tiles(128, 128) >= 3 * (int64_t) n_cu) { bm = 128; bn = 128; }
     else if (tiles(128, 64) >= 2 * (int64_t) n_cu) { bm = 128; bn = 64; }
     // ... or 128 x 128 tiles on K pieces (partial sums behind the activation copy in the scratch buffer, added up by k_mmq_reduce)
@@ -375,6 +381,9 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     if (splits > 1 && workspace_bytes < part_off + (size_t) splits * (size_t) n * (size_t) m * 4) splits = 1;
     float * yk = y; int64_t yk_stride = y_stride; int64_t split_stride = 0;
     if (splits > 1) { bm = 128; bn = 128; yk = (float *) ((char *) workspace + part_off); yk_stride = 4 * m; split_stride = n * m; }
+    // 128 x 256 tiles (8 waves, one workgroup per CU): when the token count fills them and the 128-row tiles (x K pieces) still cover the chip
+    if (!moe.tile_expert && bm == 128 && bn == 128 && n >= 256 && wide_env != 0 && (wide_env == 1 || wide_type) &&
+        ((m + 127) / 128) * ((n + 255) / 256) * splits >= (int64_t) n_cu) bn = 256;
     const dim3 grid((unsigned) ((m + bm - 1) / bm), (unsigned) ((n + bn - 1) / bn), (unsigned) splits);
 #define MI355Q_MMQ_LAUNCH(T, BM, BN) {                                                                                             \
         constexpr size_t lds_bytes = (size_t) (BM + BN) * MMQ_LDS_STRIDE;          /* 68 / 51 / 34 KiB */                           \
@@ -385,9 +394,9 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
                 return MI355Q_ERR_HIP;                                                                                             \
             attr_set[dev_] = true;                                                                                                 \
         }                                                                                                                          \
-        hipLaunchKernelGGL((k_mmq_bf16<T, BM, BN>), grid, dim3(MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride,     \
+        hipLaunchKernelGGL((k_mmq_bf16<T, BM, BN>), grid, dim3(BN == 256 ? 512 : MMQ_THREADS), lds_bytes, stream, (const uint8_t *) w, w_stride, \
                            (const uint16_t *) workspace, yk, yk_stride, (int) m, (int) n, (int) k, splits, split_stride, moe); }
-#define MI355Q_MMQ_CASE(T) case T: if (bm == 128 && bn == 128) MI355Q_MMQ_LAUNCH(T, 128, 128) else if (bm == 128) MI355Q_MMQ_LAUNCH(T, 128, 64) else MI355Q_MMQ_LAUNCH(T, 64, 64) break;
+#define MI355Q_MMQ_CASE(T) case T: if (bm == 128 && bn == 256) MI355Q_MMQ_LAUNCH(T, 128, 256) else if (bm == 128 && bn == 128) MI355Q_MMQ_LAUNCH(T, 128, 128) else if (bm == 128) MI355Q_MMQ_LAUNCH(T, 128, 64) else MI355Q_MMQ_LAUNCH(T, 64, 64) break;
     switch (type) {
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q5_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q6_K)
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q8_0) MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_0)

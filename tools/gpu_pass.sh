@@ -1,17 +1,16 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rm -rf gpurun_out/pmc_plan
-timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_SALU --output-format csv -d gpurun_out/pmc_plan/a -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pp > gpurun_out/pmc_plan_a.log 2>&1; echo "exit $?"
-timeout -k 10 400 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SMEM --output-format csv -d gpurun_out/pmc_plan/b -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pp > gpurun_out/pmc_plan_b.log 2>&1; echo "exit $?"
-python3 - <<'PY'
-import csv, glob, collections
-agg = collections.defaultdict(list)
-for f in glob.glob("gpurun_out/pmc_plan/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "k_plan" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in sorted(agg.items()):
-    print(f"{k:28s} n={len(v):3d} mean {sum(v)/len(v):.4g}")
-PY
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "mfma_tier or full_size or prefill or multi" > gpurun_out/gpu_tests_mmq.log 2>&1; rc=$?
+tail -3 gpurun_out/gpu_tests_mmq.log | cut -c1-300
+[ $rc -ne 0 ] && { tail -60 gpurun_out/gpu_tests_mmq.log | cut -c1-300; exit 1; }
+for wide in 0 -1 1; do
+echo "== MI355Q_MMQ_BF16_WIDE=$wide"
+if [ $wide = -1 ]; then unset MI355Q_MMQ_BF16_WIDE; else export MI355Q_MMQ_BF16_WIDE=$wide; fi
+timeout -k 10 120 python tools/pp_one.py q6_k 4096 14336 512 2>/dev/null
+timeout -k 10 120 python tools/pp_one.py q6_k 128256 4096 512 2>/dev/null
+timeout -k 10 120 python tools/pp_one.py q5_k 14336 4096 512 2>/dev/null
+timeout -k 10 120 python tools/pp_one.py q4_0 14336 4096 512 2>/dev/null
+timeout -k 10 120 python tools/pp_one.py q6_k 4096 14336 2048 2>/dev/null
+done
 exit 0
