@@ -371,7 +371,8 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
     auto tiles = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
     int bm = 64, bn = 64;                                     // measured on pp512 shapes: 128x128 wins from ~1.5 workgroups per CU on
     static const int wide_env = getenv("MI355Q_MMQ_BF16_WIDE") ? atoi(getenv("MI355Q_MMQ_BF16_WIDE")) : -1;      // dev: 0 = never, 1 = whenever n >= 256
-    const bool wide_type = type == MI355Q_TYPE_Q6_K || type == MI355Q_TYPE_Q5_K;                                  // (the types whose dequantization dominates)
+    // (Q6_K, whose dequantization dominates: 4096x14336 at N = 512 369 -> 425 TFLOP/s, 128256x4096 411 -> 496; Q5_K measures the same either way)
+    const bool wide_type = type == MI355Q_TYPE_Q6_K;
     if (2 * tiles(128, 128) >= 3 * (int64_t) n_cu) { bm = 128; bn = 128; }
     else if (tiles(128, 64) >= 2 * (int64_t) n_cu) { bm = 128; bn = 64; }
     // ... or 128 x 128 tiles on K pieces (partial sums behind the activation copy in the scratch buffer, added up by k_mmq_reduce)

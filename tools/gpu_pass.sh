@@ -1,16 +1,8 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "mfma_tier or full_size or prefill or multi" > gpurun_out/gpu_tests_mmq.log 2>&1; rc=$?
-tail -3 gpurun_out/gpu_tests_mmq.log | cut -c1-300
-[ $rc -ne 0 ] && { tail -60 gpurun_out/gpu_tests_mmq.log | cut -c1-300; exit 1; }
-for wide in 0 -1 1; do
-echo "== MI355Q_MMQ_BF16_WIDE=$wide"
-if [ $wide = -1 ]; then unset MI355Q_MMQ_BF16_WIDE; else export MI355Q_MMQ_BF16_WIDE=$wide; fi
-timeout -k 10 120 python tools/pp_one.py q6_k 4096 14336 512 2>/dev/null
-timeout -k 10 120 python tools/pp_one.py q6_k 128256 4096 512 2>/dev/null
-timeout -k 10 120 python tools/pp_one.py q5_k 14336 4096 512 2>/dev/null
-timeout -k 10 120 python tools/pp_one.py q4_0 14336 4096 512 2>/dev/null
-timeout -k 10 120 python tools/pp_one.py q6_k 4096 14336 2048 2>/dev/null
-done
+timeout -k 10 300 python tools/ppbench.py > gpurun_out/ppbench.log 2>&1; tail -8 gpurun_out/ppbench.log
+export GGML_BACKEND_PATH=$GRAFT_REPO_ROOT/llama.cpp.dsp_amd/lib/libggml-mi355.so
+timeout -k 10 300 oracle/_ref/avx2/model_parity --preset 8b --layers 32 --vocab 128256 --tokens 1 --no-cpu --pp 512 2>&1 | grep "prefill through"
+timeout -k 10 900 python -m pytest tests/test_plugin.py -m gpu -x -q -k "backend_ops" > gpurun_out/gpu_tests_plugin.log 2>&1; tail -2 gpurun_out/gpu_tests_plugin.log | cut -c1-200
 exit 0
