@@ -321,6 +321,27 @@ def test_q8_0_prefill_multi_and_unaligned_fall_back(G, torch, orc):
     check(G, t, K, 20, gpu_mul_mat(G, torch, t, w, x, 64, K), orc.mul_mat(t, w, x, 64, 20, K), "K=384")
 
 
+def test_q6_k_wide_token_tile(G, torch, orc):
+    """Q6_K batches of >= 256 tokens run 128 x 256 tiles (8 waves; csrc/mmq_bf16.hip) when those still cover the chip.  An output element's
+    k-order does not depend on the tile shape, so the first 200 tokens of a ragged 300-token batch must equal the same tokens multiplied alone
+    (200 < 256: the 128-token tile) bit for bit; and the usual bounds against the oracle and the exact product hold."""
+    t, M, K = oracle.Q6_K, 16384, 2048
+    rng = np.random.default_rng(77)
+    w = quantized_weights(t, M, K, rng)
+    x = (rng.standard_normal((300, K)) * 1.7).astype(np.float32)
+    assert on_mfma_tier(G, t, K, 300)
+    wq = G.QWeight.from_host(t, w, M, K)
+    y = G.mul_mat(wq, torch.from_numpy(x).cuda()).cpu().numpy()
+    y200 = G.mul_mat(wq, torch.from_numpy(x[:200].copy()).cuda()).cpu().numpy()
+    assert np.isfinite(y).all()
+    assert np.array_equal(y[:200].view(np.uint32), y200.view(np.uint32))
+    rows = np.unique(rng.integers(0, M, 40)); cols = np.unique(np.concatenate([rng.integers(0, 300, 10), [255, 256, 299]]))
+    ref = orc.mul_mat(t, w[rows], x[cols], len(rows), len(cols), K)
+    assert nmse(y[np.ix_(cols, rows)], ref) <= 5e-4
+    exact = x.astype(np.float64) @ orc.dequantize(t, w, K).astype(np.float64).T
+    assert nmse(y, exact) <= 2e-5
+
+
 def test_mfma_tier_ragged_and_alignment_fallback(G, torch, orc):
     """M not a multiple of the 128-row tile, N not a multiple of the 128-token tile; and an output whose rows are
     not 16-byte aligned (M % 4 != 0) must silently take the GEMV tier (exact) instead of the f32x4 epilogue."""
