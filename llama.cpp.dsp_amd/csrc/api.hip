@@ -12,6 +12,10 @@ namespace mi355q {
 // kernels (other translation units)
 int launch_quantize_act(int act_type, const float * x, int64_t x_stride, void * out, int64_t n, int64_t k, int flags, hipStream_t stream);
 struct GenericMoe { const int32_t * ids; int64_t ids_stride; int64_t expert_stride; int n_used; int x_ne1; int n_expert; int pad; };
+bool mmq_generic_supported(int type, int64_t k);
+size_t mmq_generic_workspace(int64_t n, int64_t k);
+int launch_mmq_generic(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
+                       int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, hipStream_t stream);
 int launch_gemv_generic(int type, const void * w, int64_t w_stride, const void * act, int64_t act_stride,
                         float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, hipStream_t stream, const GenericMoe * moe);
 struct MoeArgs { const int32_t * ids; int64_t ids_stride; int64_t expert_stride; int64_t x_stride2; int n_used; int x_ne1; int n_expert; int n_pairs; };
@@ -302,7 +306,10 @@ size_t mi355q_mul_mat_workspace(int type, int64_t m, int64_t n, int64_t k) {
     if (!t || t->act < 0 || k % t->blck) return 0;
     // GEMV tier: fused prologue, no scratch; matrix-core tiers: the prepared activations (+ split-K partial sums for shapes that are cut along K)
     if (is_planar(t, k)) return mmq_supported(type, k) && n > 8 ? mmq_workspace(n, k) + (mmq_i8_supported(type, k) ? mmq_i8_split_workspace(m, n, k, cu_count()) : mmq_split_workspace(m, n, k, cu_count())) : (mmq_supported(type, k) ? mmq_workspace(n, k) : 0);
-    return (size_t) align256(mi355q_row_size(t->act, k) * n);
+    // canonical rows: quantized activations for the per-column tier; bf16 activations for the batched tier (mmq_generic.hip)
+    const size_t cols = (size_t) align256(mi355q_row_size(t->act, k) * n);
+    const size_t batched = n > 8 && mmq_generic_supported(type, k) ? mmq_generic_workspace(n, k) : 0;
+    return cols > batched ? cols : batched;
 }
 
 static int mul_mat_checks(const TypeInfo * t, const void * w, int64_t w_stride, const float * x, int64_t x_stride,
@@ -381,6 +388,13 @@ int mi355q_mul_mat_multi(const mi355q_mat * mats, int n_mats, const float * x, i
         const TypeInfo * t = type_info(mats[i].type);
         if (is_planar(t, k)) {
             MQ_TRY(mi355q_mul_mat_multi(&mats[i], 1, x, x_stride, n, k, workspace, workspace_bytes, flags, stream));
+            continue;
+        }
+        // canonical rows at batch sizes: every weight decoded once per 64 tokens and multiplied on the matrix cores (bf16), instead of one
+        // GEMV column per token (MI355Q_FLAG_FORCE_GEMV / _FORCE_GENERIC keep the per-column tier with the CPU's integer arithmetic)
+        if (n > 8 && !(flags & (MI355Q_FLAG_FORCE_GEMV | MI355Q_FLAG_FORCE_GENERIC)) && mmq_generic_supported(mats[i].type, k) && !((uintptr_t) x & 3) && !(x_stride & 3)) {
+            if (!workspace || workspace_bytes < mmq_generic_workspace(n, k)) return fail(MI355Q_ERR_WORKSPACE, "mul_mat: workspace %zu < %zu", workspace_bytes, mmq_generic_workspace(n, k));
+            MQ_TRY(launch_mmq_generic(mats[i].type, mats[i].w, mats[i].w_stride, x, x_stride, mats[i].y, mats[i].y_stride, mats[i].m, n, k, workspace, workspace_bytes, st));
             continue;
         }
         const int64_t arow = mi355q_row_size(t->act, k);

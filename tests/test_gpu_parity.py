@@ -62,9 +62,18 @@ def nmse(y, ref):
 MMQ_TYPES = (oracle.Q4_K, oracle.Q5_K, oracle.Q6_K, oracle.Q8_0, oracle.Q4_0)
 
 
+BLOCK32_TYPES = (oracle.Q4_0, oracle.Q4_1, oracle.Q5_0, oracle.Q5_1, oracle.Q8_0, oracle.IQ4_NL)
+CANONICAL_BATCH_TYPES = BLOCK32_TYPES + (oracle.Q2_K, oracle.Q3_K, oracle.IQ2_XXS, oracle.IQ2_XS, oracle.IQ2_S, oracle.IQ3_XXS, oracle.IQ3_S, oracle.IQ1_S, oracle.IQ1_M)
+
+
 def on_mfma_tier(G, t, K, N):
-    """Mirror of the library's tier choice (csrc/api.hip use_mmq): planar rows, N > 8, K a multiple of the MFMA step."""
-    return N > 8 and t in MMQ_TYPES and G.is_planar(t, K) and K % (256 if t in (oracle.Q4_K, oracle.Q5_K, oracle.Q6_K) else 128) == 0
+    """Mirror of the library's tier choice (csrc/api.hip): N > 8 and either planar rows of a type with a matrix-core kernel (K a multiple of its
+    MFMA step) or canonical rows of a type the batched canonical tier decodes (csrc/mmq_generic.hip; K a multiple of 128 / of the 256-block)."""
+    if N <= 8:
+        return False
+    if G.is_planar(t, K):
+        return t in MMQ_TYPES and K % (256 if t in (oracle.Q4_K, oracle.Q5_K, oracle.Q6_K) else 128) == 0
+    return t in CANONICAL_BATCH_TYPES and K % (128 if t in BLOCK32_TYPES else 256) == 0
 
 
 def check(G, t, K, N, y, ref, what=""):
@@ -340,6 +349,30 @@ def test_q6_k_wide_token_tile(G, torch, orc):
     assert nmse(y[np.ix_(cols, rows)], ref) <= 5e-4
     exact = x.astype(np.float64) @ orc.dequantize(t, w, K).astype(np.float64).T
     assert nmse(y, exact) <= 2e-5
+
+
+@pytest.mark.parametrize("t", CANONICAL_BATCH_TYPES, ids=ids_t)
+def test_canonical_rows_batched_tier(G, torch, orc, t):
+    """The 12 types without a planar layout (and the 32-block types at a K that keeps their rows canonical) at batch sizes: every weight is decoded
+    once per 64 tokens to the value dequantize_row_<type> gives it, rounded to bf16 and multiplied on the matrix cores (csrc/mmq_generic.hip) --
+    NMSE <= 2e-5 against the exact product of the dequantized weights, <= 5e-4 against the CPU arithmetic (the reference's op bound); ragged M and N;
+    MI355Q_FLAG_FORCE_GEMV keeps the per-column tier, which reproduces the CPU's integer arithmetic."""
+    rng = np.random.default_rng(300 + t)
+    for M, N, K in ((200, 70, 384 if t in BLOCK32_TYPES else 512), (64, 9, 128 * 6 if t in BLOCK32_TYPES else 1024)):
+        if G.is_planar(t, K):
+            continue
+        w = quantized_weights(t, M, K, rng)
+        x = (rng.standard_normal((N, K)) * 1.3).astype(np.float32)
+        assert on_mfma_tier(G, t, K, N)
+        y = gpu_mul_mat(G, torch, t, w, x, M, K)
+        assert np.isfinite(y).all()
+        exact = x.astype(np.float64) @ orc.dequantize(t, w, K).astype(np.float64).T
+        e = nmse(y, exact)
+        assert e <= 2e-5, f"{ids_t(t)} {M}x{N}x{K}: NMSE vs exact {e:.3e}"
+        ref = orc.mul_mat(t, w, x, M, N, K)
+        assert nmse(y, ref) <= 5e-4
+        yg = gpu_mul_mat(G, torch, t, w, x, M, K, flags=0x4)              # MI355Q_FLAG_FORCE_GEMV
+        check_close(yg, ref, f"{ids_t(t)} per-column tier")
 
 
 def test_mfma_tier_ragged_and_alignment_fallback(G, torch, orc):
