@@ -15,7 +15,7 @@ struct GenericMoe { const int32_t * ids; int64_t ids_stride; int64_t expert_stri
 bool mmq_generic_supported(int type, int64_t k);
 size_t mmq_generic_workspace(int64_t n, int64_t k);
 int launch_mmq_generic(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                       int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, hipStream_t stream);
+                       int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, hipStream_t stream, const MoeTiles * moe = nullptr);
 int launch_gemv_generic(int type, const void * w, int64_t w_stride, const void * act, int64_t act_stride,
                         float * y, int64_t y_stride, int64_t m, int64_t n, int64_t k, hipStream_t stream, const GenericMoe * moe);
 struct MoeArgs { const int32_t * ids; int64_t ids_stride; int64_t expert_stride; int64_t x_stride2; int n_used; int x_ne1; int n_expert; int n_pairs; };
@@ -131,6 +131,7 @@ static int moe_tile(int type, int64_t k, int64_t pairs, int64_t n_expert) {
     if (forced == 64 || forced == 128) return forced;
     static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr, no_q80 = getenv("MI355Q_NO_MMQ_Q80") != nullptr;
     const bool integer_tier = (!no_i8 && mmq_i8_supported(type, k)) || (!no_q80 && mmq_q80_supported(type, k));
+    if (!mmq_supported(type, k)) return 64;                     // canonical rows (mmq_generic.hip): 64-token tiles
     return integer_tier ? 64 : 128;
 }
 static int64_t moe_slots(int type, int64_t k, int64_t pairs, int64_t n_expert) {     // gathered rows incl. the alignment padding of every segment, a multiple of 128
@@ -144,6 +145,10 @@ static size_t moe_grouped_workspace(int type, int64_t m, int64_t k, int64_t pair
 }
 static bool moe_grouped_ok(int type, int64_t m, int64_t k, const void * x, int64_t x_stride1, int64_t x_stride2) {
     return mmq_supported(type, k) && m % 4 == 0 && k % 4 == 0 && !(((uintptr_t) x | (uintptr_t) x_stride1 | (uintptr_t) x_stride2) & 15);
+}
+// canonical rows: the grouped form runs on the batched canonical tier
+static bool moe_grouped_canonical_ok(const TypeInfo * t, int type, int64_t k, const void * x, int64_t x_stride1, int64_t x_stride2) {
+    return !is_planar(t, k) && mmq_generic_supported(type, k) && k % 4 == 0 && !(((uintptr_t) x | (uintptr_t) x_stride1 | (uintptr_t) x_stride2) & 15);
 }
 } // namespace mi355q
 
@@ -416,7 +421,7 @@ int mi355q_mul_mat(int type, const void * w, int64_t w_stride, const float * x, 
 size_t mi355q_mul_mat_id_workspace(int type, int64_t m, int64_t k, int64_t n_used, int64_t n_tok, int64_t x_ne1, int64_t n_expert) {
     const TypeInfo * t = type_info(type);
     if (!t || t->act < 0 || k % t->blck) return 0;
-    const size_t grouped = n_used * n_tok >= MOE_GROUPED_MIN_PAIRS && is_planar(t, k) && mmq_supported(type, k) && m % 4 == 0 ? moe_grouped_workspace(type, m, k, n_used * n_tok, n_expert < 1 ? 1 : (n_expert > 1024 ? 1024 : n_expert)) : 0;
+    const size_t grouped = n_used * n_tok >= MOE_GROUPED_MIN_PAIRS && ((is_planar(t, k) && mmq_supported(type, k) && m % 4 == 0) || (!is_planar(t, k) && mmq_generic_supported(type, k))) ? moe_grouped_workspace(type, m, k, n_used * n_tok, n_expert < 1 ? 1 : (n_expert > 1024 ? 1024 : n_expert)) : 0;
     if (is_planar(t, k)) return grouped;
     const size_t generic = (size_t) align256(mi355q_row_size(t->act, k) * n_tok * x_ne1);
     return grouped > generic ? grouped : generic;
@@ -435,8 +440,10 @@ int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert
     if (pairs == 0 || m == 0) return MI355Q_OK;
     if (pairs > 65535) return fail(MI355Q_ERR_UNSUPPORTED, "mul_mat_id: more than 65535 (token,slot) pairs per call");
     hipStream_t st = (hipStream_t) stream;
-    if (pairs >= MOE_GROUPED_MIN_PAIRS && is_planar(t, k) && n_expert <= 1024 && moe_grouped_ok(type, m, k, x, x_stride1, x_stride2) && !((uintptr_t) y & 15) &&
-        !(((uintptr_t) w | (uintptr_t) w_stride | (uintptr_t) expert_stride) & 15)) {
+    const bool grouped_canonical = moe_grouped_canonical_ok(t, type, k, x, x_stride1, x_stride2);
+    if (pairs >= MOE_GROUPED_MIN_PAIRS && n_expert <= 1024 &&
+        (grouped_canonical || (is_planar(t, k) && moe_grouped_ok(type, m, k, x, x_stride1, x_stride2) && !((uintptr_t) y & 15) &&
+                               !(((uintptr_t) w | (uintptr_t) w_stride | (uintptr_t) expert_stride) & 15)))) {
         // Prefill-sized batches: rows grouped by expert ON THE DEVICE, one launch of the matrix-core tier over all experts (see k_moe_sort)
         const size_t need = moe_grouped_workspace(type, m, k, pairs, n_expert);
         if (!workspace || workspace_bytes < need) return fail(MI355Q_ERR_WORKSPACE, "mul_mat_id: workspace %zu < %zu for the grouped form", workspace_bytes, need);
@@ -453,7 +460,9 @@ int mi355q_mul_mat_id(int type, const void * w, int64_t w_stride, int64_t expert
         const MoeTiles mt = { d_tile, d_seg_end, expert_stride, tile, 0, d_order };
         static const bool no_i8 = getenv("MI355Q_NO_MMQ_I8") != nullptr;
         static const bool no_q80g = getenv("MI355Q_NO_MMQ_Q80") != nullptr;
-        if (!no_i8 && mmq_i8_supported(type, k)) {
+        if (grouped_canonical) {
+            MQ_TRY(launch_mmq_generic(type, w, w_stride, xg, 4 * k, y, 4 * m, m, slots, k, wsp, ws_left, st, &mt));
+        } else if (!no_i8 && mmq_i8_supported(type, k)) {
             const mi355q_mat one = { type, w, w_stride, y, 4 * m, m };
             MQ_TRY(launch_mmq_i8_multi(&one, 1, xg, 4 * k, slots, k, wsp, ws_left, cu_count(), st, true, &mt));
         } else if (!no_q80g && mmq_q80_supported(type, k)) {

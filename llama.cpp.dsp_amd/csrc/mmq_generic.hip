@@ -175,12 +175,19 @@ __device__ __forceinline__ uint32_t gq_pack(float a, float b) {
 template <int TYPE>
 __global__ void __launch_bounds__(256, 2)
 k_mmq_generic(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __restrict__ xb /* bf16 [n][k] */, float * __restrict__ y, int64_t y_stride,
-              int m, int n, int k) {
+              int m, int n, int k, const MoeTiles moe) {
     __shared__ __attribute__((aligned(16))) uint8_t Ws[GQ_BM * GQ_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t Xs[GQ_BN * GQ_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int quarter = tid & 3, r = tid >> 2;
     const int m0 = blockIdx.x * GQ_BM, n0 = blockIdx.y * GQ_BN;
+    if (moe.tile_expert) {                                    // grouped MUL_MAT_ID: this token tile's expert (uniform per workgroup), as the other tiers
+        const int e = moe.tile_expert[n0 / moe.tile_tokens];
+        if (e < 0) return;
+        w += (int64_t) e * moe.expert_stride;
+        n = moe.seg_end[e];
+        if (n0 >= n) return;
+    }
     const uint8_t * wrow = w + (int64_t) (m0 + r < m ? m0 + r : 0) * w_stride;
     const uint16_t * xrow = xb + (int64_t) (n0 + r < n ? n0 + r : 0) * k + 32 * quarter;
     gq_f32x4 acc[2][2];
@@ -223,7 +230,9 @@ k_mmq_generic(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t *
     for (int j = 0; j < 2; ++j) {
         const int tok = n0 + 32 * wn + 16 * j + (lane & 15);
         if (tok >= n) continue;
-        float * yr = (float *) ((char *) y + (int64_t) tok * y_stride);
+        const int dr = moe.dst_row ? moe.dst_row[tok] : tok;                  // grouped MUL_MAT_ID: straight to the pair's row of the result
+        if (dr < 0) continue;
+        float * yr = (float *) ((char *) y + (int64_t) dr * y_stride);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int mr = m0 + 32 * wm + 16 * i + 4 * (lane >> 4);
@@ -257,7 +266,8 @@ __global__ void __launch_bounds__(256) k_gq_x_to_bf16(const float * __restrict__
 
 // w: CANONICAL device rows; x f32 [n][k] (row stride x_stride); workspace >= mmq_generic_workspace(n, k); y f32 [n][m]
 int launch_mmq_generic(int type, const void * w, int64_t w_stride, const float * x, int64_t x_stride, float * y, int64_t y_stride,
-                       int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, hipStream_t stream) {
+                       int64_t m, int64_t n, int64_t k, void * workspace, size_t workspace_bytes, hipStream_t stream, const MoeTiles * moe_p = nullptr) {
+    MoeTiles moe = {}; if (moe_p) moe = *moe_p;
     if (!mmq_generic_supported(type, k)) return MI355Q_ERR_UNSUPPORTED;
     if (m <= 0 || n <= 0) return MI355Q_OK;
     if (workspace_bytes < mmq_generic_workspace(n, k) || ((uintptr_t) workspace & 15)) return MI355Q_ERR_WORKSPACE;
@@ -265,7 +275,7 @@ int launch_mmq_generic(int type, const void * w, int64_t w_stride, const float *
     const int cgrid = (int) ((pairs + 255) / 256 < 8192 ? (pairs + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_gq_x_to_bf16, dim3(cgrid), dim3(256), 0, stream, x, x_stride, (uint32_t *) workspace, n, k);
     const dim3 grid((unsigned) ((m + GQ_BM - 1) / GQ_BM), (unsigned) ((n + GQ_BN - 1) / GQ_BN));
-#define MI355Q_GQ_CASE(T) case T: hipLaunchKernelGGL((k_mmq_generic<T>), grid, dim3(256), 0, stream, (const uint8_t *) w, w_stride, (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k); break;
+#define MI355Q_GQ_CASE(T) case T: hipLaunchKernelGGL((k_mmq_generic<T>), grid, dim3(256), 0, stream, (const uint8_t *) w, w_stride, (const uint16_t *) workspace, y, y_stride, (int) m, (int) n, (int) k, moe); break;
     switch (type) {
         MI355Q_GQ_CASE(MI355Q_TYPE_Q4_0) MI355Q_GQ_CASE(MI355Q_TYPE_Q4_1) MI355Q_GQ_CASE(MI355Q_TYPE_Q5_0) MI355Q_GQ_CASE(MI355Q_TYPE_Q5_1)
         MI355Q_GQ_CASE(MI355Q_TYPE_Q8_0) MI355Q_GQ_CASE(MI355Q_TYPE_IQ4_NL) MI355Q_GQ_CASE(MI355Q_TYPE_Q2_K) MI355Q_GQ_CASE(MI355Q_TYPE_Q3_K)

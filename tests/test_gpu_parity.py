@@ -415,12 +415,13 @@ def test_multi_equals_single(G, torch, orc):
 # ------------------------------------------------------------------------------------------------
 # MoE (tests/test-backend-ops.cpp:4240-4270 shapes: n_mats {4,8} x n_used {1,2,4}, m=512, k=256)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.Q8_0, oracle.Q5_K, oracle.IQ4_XS, oracle.Q4_1], ids=ids_t)
+@pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.Q8_0, oracle.Q5_K, oracle.IQ4_XS, oracle.Q4_1, oracle.IQ3_S, oracle.Q2_K], ids=ids_t)
 @pytest.mark.parametrize("cfg", [(4, 1, 1), (8, 2, 1), (8, 4, 5), (4, 2, 32), (8, 2, 160)], ids=str)
 def test_mul_mat_id(G, torch, orc, t, cfg):
     """(n_expert, n_used, n_tokens).  Up to 16 (token, slot) pairs every pair is one exact GEMV column with the ids read on the device;
     above that the pairs are counting-sorted by expert ON THE DEVICE and one launch of the matrix-core tier walks all experts (csrc/api.hip):
-    Q4_K and Q8_0 still reproduce the CPU arithmetic (integer tiers; Q8_0 bit for bit), the bf16 tier is held to the reference's op bound."""
+    Q4_K and Q8_0 still reproduce the CPU arithmetic (integer tiers; Q8_0 bit for bit), the bf16 tiers -- planar rows, and canonical rows on the
+    batched canonical tier (Q4_1, IQ3_S, Q2_K here) -- are held to the reference's op bound."""
     ne, nu, nt = cfg
     rng = np.random.default_rng(17 * t + ne + nu + nt)
     for K, M in ((256, 512), (2048, 96)):
