@@ -185,6 +185,62 @@ template <> struct W32<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]
     }
 };
 
+// ---- IQ4_NL / IQ4_XS: 4-bit indices into the 16-entry non-linear code book (kvalues_iq4nl) ----
+// four nibbles held as bytes of a dword -> four int8 code-book values: two v_perm_b32 + a select on bit 3 (as gemv_stream.cuh iq4_lut4)
+__device__ __forceinline__ uint32_t mmq_iq4_lut4(uint32_t nib) {
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t a = __builtin_amdgcn_perm(0xF6EADDCFu, 0xBFAD9881u, sel);      // entries 0..7:  -127,-104,-83,-65,-49,-35,-22,-10
+    const uint32_t b = __builtin_amdgcn_perm(0x71594535u, 0x26190D01u, sel);      // entries 8..15: 1,13,25,38,53,69,89,113
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
+    return (a & ~m) | (b & m);
+}
+// 4 SIGNED bytes of a dword -> a*byte as 4 floats -> 2 packed bf16 dwords
+__device__ __forceinline__ void sbytes4_to_bf16(uint32_t v, float a, uint32_t & lo, uint32_t & hi) {
+    const f32x2p q01 = { (float) (int8_t) (v & 0xFFu), (float) (int8_t) ((v >> 8) & 0xFFu) };
+    const f32x2p q23 = { (float) (int8_t) ((v >> 16) & 0xFFu), (float) (int8_t) (v >> 24) };
+    const f32x2p aa = { a, a };
+    const f32x2p w01 = q01 * aa, w23 = q23 * aa;
+    lo = pack_bf16(w01.x, w01.y); hi = pack_bf16(w23.x, w23.y);
+}
+template <> struct W32<MI355Q_TYPE_IQ4_NL> {        // planar [qs 16*nb][d 2*nb]; 32 k = 1 block: low nibbles = first 16, high = last 16
+    W32_DEQUANT16
+    uint4 q0; uint32_t dh;
+    __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
+        const int b = 2 * ks + sub;
+        q0 = ldg16_nt(row + 16 * (int64_t) b);
+        dh = *(const uint16_t *) (row + 16 * (int64_t) nb + 2 * b);
+    }
+    __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_iq4_nl, ggml-quants.c:2436-2452: y = d * kvalues_iq4nl[nibble]
+        const float d = h2f(dh);
+        const uint32_t qw[4] = { q0.x, q0.y, q0.z, q0.w };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sbytes4_to_bf16(mmq_iq4_lut4(qw[i] & 0x0F0F0F0Fu), d, out[2 * i], out[2 * i + 1]);
+            sbytes4_to_bf16(mmq_iq4_lut4((qw[i] >> 4) & 0x0F0F0F0Fu), d, out[8 + 2 * i], out[8 + 2 * i + 1]);
+        }
+    }
+};
+template <> struct W32<MI355Q_TYPE_IQ4_XS> {        // planar [qs 128*nb][hdr 8*nb: d, scales_h, scales_l[4]]; 32 k = sub-block ib of block b
+    W32_DEQUANT16
+    uint4 q0; uint2 h; int ib;
+    __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
+        const int b = ks >> 2; ib = 2 * (ks & 3) + sub;
+        q0 = ldg16_nt(row + 128 * (int64_t) b + 16 * ib);
+        h  = *(const uint2 *) (row + 128 * (int64_t) nb + 8 * b);
+    }
+    __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_iq4_xs, ggml-quants.c:2454-2475: dl = d * (ls - 32)
+        const uint32_t scales_h = h.x >> 16;
+        const int ls = (int) ((h.y >> (8 * (ib >> 1) + 4 * (ib & 1))) & 0x0Fu) | (int) (((scales_h >> (2 * ib)) & 3u) << 4);
+        const float dl = h2f(h.x & 0xFFFFu) * (float) (ls - 32);
+        const uint32_t qw[4] = { q0.x, q0.y, q0.z, q0.w };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sbytes4_to_bf16(mmq_iq4_lut4(qw[i] & 0x0F0F0F0Fu), dl, out[2 * i], out[2 * i + 1]);
+            sbytes4_to_bf16(mmq_iq4_lut4((qw[i] >> 4) & 0x0F0F0F0Fu), dl, out[8 + 2 * i], out[8 + 2 * i + 1]);
+        }
+    }
+};
+
 // ---- the kernel ---------------------------------------------------------------------------------
 // Tile BM x BN x 128; 256 threads = 2 x 2 waves, each a (BM/2) x (BN/2) output tile of 16x16x32 MFMAs.  Thread jobs per
 // K-step: BM*4/256 dequant units (row, 32-k quarter) and BN*4/256 activation quarters (64 B).  Shapes that would leave
@@ -213,7 +269,7 @@ k_mmq_bf16(const uint8_t * __restrict__ w, int64_t w_stride, const uint16_t * __
         w += (int64_t) e * moe.expert_stride;
         n = moe.seg_end[e];
     }
-    const int nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
+    const int nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? k >> 5 : k >> 8;
     // split K (blockIdx.z): a shape whose 128 x 128 tiles do not fill the chip is cut along K instead of into smaller tiles (each weight is
     // then dequantized for 128 tokens, not 64); piece z writes its partial sums to y + z * split_stride, k_mmq_reduce adds them in order
     const int steps_all = k / MMQ_BK;
@@ -327,8 +383,8 @@ void launch_mmq_reduce(const float * part, int n_split, int64_t split_stride, fl
 // ---- host side ------------------------------------------------------------------------------------
 bool mmq_supported(int type, int64_t k) {
     switch (type) {
-    case MI355Q_TYPE_Q4_K: case MI355Q_TYPE_Q5_K: case MI355Q_TYPE_Q6_K: return k % 256 == 0;
-    case MI355Q_TYPE_Q8_0: case MI355Q_TYPE_Q4_0: return k % 128 == 0;
+    case MI355Q_TYPE_Q4_K: case MI355Q_TYPE_Q5_K: case MI355Q_TYPE_Q6_K: case MI355Q_TYPE_IQ4_XS: return k % 256 == 0;
+    case MI355Q_TYPE_Q8_0: case MI355Q_TYPE_Q4_0: case MI355Q_TYPE_IQ4_NL: return k % 128 == 0;
     default: return false;
     }
 }
@@ -400,7 +456,7 @@ int launch_mmq_bf16(int type, const void * w, int64_t w_stride, const float * x,
 #define MI355Q_MMQ_CASE(T) case T: if (bm == 128 && bn == 256) MI355Q_MMQ_LAUNCH(T, 128, 256) else if (bm == 128 && bn == 128) MI355Q_MMQ_LAUNCH(T, 128, 128) else if (bm == 128) MI355Q_MMQ_LAUNCH(T, 128, 64) else MI355Q_MMQ_LAUNCH(T, 64, 64) break;
     switch (type) {
         MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q5_K) MI355Q_MMQ_CASE(MI355Q_TYPE_Q6_K)
-        MI355Q_MMQ_CASE(MI355Q_TYPE_Q8_0) MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_0)
+        MI355Q_MMQ_CASE(MI355Q_TYPE_Q8_0) MI355Q_MMQ_CASE(MI355Q_TYPE_Q4_0) MI355Q_MMQ_CASE(MI355Q_TYPE_IQ4_NL) MI355Q_MMQ_CASE(MI355Q_TYPE_IQ4_XS)
     default: return MI355Q_ERR_UNSUPPORTED;
     }
 #undef MI355Q_MMQ_CASE
