@@ -94,9 +94,11 @@ __device__ __forceinline__ float sub_dot(const uint8_t * wrow, const uint8_t * a
             }
             return (ld_h(w + 208) * yd) * (float) (scs[0] * sa + scs[1] * sb);
         } else if constexpr (TYPE == MI355Q_TYPE_Q3_K) {            // :6604-6661
+            // blocks are 110 bytes: 2-byte aligned.  16-bit loads + v_dot4: q - 4 (1 - hbit) = (low2 | hbit << 2) - 4, and sum (v - 4) y = sum v y - 4 bsum
             const uint8_t * w = wrow + b * 110;
             const int h = j >> 2, c = j & 3;
-            const uint8_t * qs = w + 32 + 32 * h; const uint8_t * hm = w; const uint8_t * sp = w + 96;
+            const uint16_t * qs = (const uint16_t *) (w + 32 + 32 * h); const uint16_t * hm = (const uint16_t *) w; const uint8_t * sp = w + 96;
+            const uint32_t * y4 = (const uint32_t *) y;
             int sc[2];
             for (int t = 0; t < 2; ++t) {
                 const int jj = 2 * j + t;
@@ -105,20 +107,26 @@ __device__ __forceinline__ float sub_dot(const uint8_t * wrow, const uint8_t * a
                 sc[t] = (lo | (hi << 4)) - 32;
             }
             int sa = 0, sb = 0;
-            for (int l = 0; l < 32; ++l) {
-                const int q = ((qs[l] >> (2 * c)) & 3) - (((hm[l] >> (4 * h + c)) & 1) ? 0 : 4);
-                if (l < 16) sa += q * y[l]; else sb += q * y[l];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t q4 = (uint32_t) qs[2 * i] | ((uint32_t) qs[2 * i + 1] << 16), h4 = (uint32_t) hm[2 * i] | ((uint32_t) hm[2 * i + 1] << 16);
+                const uint32_t v = ((q4 >> (2 * c)) & 0x03030303u) | (((h4 >> (4 * h + c)) & 0x01010101u) << 2);
+                if (i < 4) sa = __builtin_amdgcn_sdot4((int) v, (int) y4[i], sa, false); else sb = __builtin_amdgcn_sdot4((int) v, (int) y4[i], sb, false);
             }
+            sa -= 4 * bs0; sb -= 4 * bs1;
             return (ld_h(w + 108) * yd) * (float) (sc[0] * sa + sc[1] * sb);
         } else if constexpr (TYPE == MI355Q_TYPE_Q2_K) {            // :5485-5523
+            // blocks are 84 bytes (4-byte aligned rows): 32-bit loads + v_dot4 on the 2-bit fields spread to bytes
             const uint8_t * w = wrow + b * 84;
             const int h = j >> 2, c = j & 3;
-            const uint8_t * qs = w + 16 + 32 * h;
+            const uint32_t * qs4 = (const uint32_t *) (w + 16 + 32 * h);
+            const uint32_t * y4 = (const uint32_t *) y;
             const int s0 = w[2 * j], s1 = w[2 * j + 1];
             int sa = 0, sb = 0;
-            for (int l = 0; l < 32; ++l) {
-                const int q = (qs[l] >> (2 * c)) & 3;
-                if (l < 16) sa += q * y[l]; else sb += q * y[l];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t v = (qs4[i] >> (2 * c)) & 0x03030303u;
+                if (i < 4) sa = __builtin_amdgcn_sdot4((int) v, (int) y4[i], sa, false); else sb = __builtin_amdgcn_sdot4((int) v, (int) y4[i], sb, false);
             }
             const float dall = yd * ld_h(w + 80), dmin = yd * ld_h(w + 82);
             return dall * (float) ((s0 & 0x0F) * sa + (s1 & 0x0F) * sb) - dmin * (float) ((s0 >> 4) * bs0 + (s1 >> 4) * bs1);
