@@ -86,6 +86,9 @@ constexpr unsigned SET_K46  = tbit(MI355Q_TYPE_Q4_K) | tbit(MI355Q_TYPE_Q6_K);
 constexpr unsigned SET_K456 = SET_K46 | tbit(MI355Q_TYPE_Q5_K);
 constexpr unsigned SET_80   = tbit(MI355Q_TYPE_Q8_0) | tbit(MI355Q_TYPE_Q4_0);
 constexpr unsigned SET_ALL  = SET_K456 | SET_80;
+// IQ4_XS / IQ4_NL models (llama-quant.cpp: IQ4_XS or IQ4_NL for most tensors, Q5_K / Q6_K for attn_v, some ffn_down and the output matrix)
+constexpr unsigned SET_IQ4  = tbit(MI355Q_TYPE_IQ4_XS) | tbit(MI355Q_TYPE_IQ4_NL) | tbit(MI355Q_TYPE_Q5_K) | tbit(MI355Q_TYPE_Q6_K);
+constexpr unsigned SET_ANY  = SET_ALL | SET_IQ4;
 
 struct PlanCursor { int gr, s; const uint8_t * row; };
 
@@ -149,7 +152,7 @@ struct StageGeom { int r_hi, nb, nchunks, steps; };
 template <int T> __device__ __forceinline__ StageGeom plan_geom(int k, int r_hi) {
     StageGeom g;
     g.r_hi = r_hi;
-    g.nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? k >> 5 : k >> 8;
+    g.nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? k >> 5 : k >> 8;
     g.nchunks = row_chunks(T, k); g.steps = (g.nchunks + 63) >> 6;
     return g;
 }
@@ -475,7 +478,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     PLAN_STAMP(1);
 
     if (flags & PLAN_F_NEW_X) {
-        constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0) ? FAM_Q80 : FAM_Q8K;
+        constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? FAM_Q80 : FAM_Q8K;
         plan_lds_barrier();                                   // all waves are done with the previous LDS image and staging area
         if (flags & PLAN_F_DIRECT) {                          // one plain vector: gathered and quantized span by span, one barrier
             const bool okd = plan_gather_direct<FAM>(st, c, k, wave, lane);
@@ -905,6 +908,8 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
             case MI355Q_TYPE_Q6_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q6_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q6_K>(st, c); break;
             case MI355Q_TYPE_Q8_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q8_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q8_0>(st, c); break;
             case MI355Q_TYPE_Q4_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_0>(st, c); break;
+            case MI355Q_TYPE_IQ4_NL: if constexpr ((SET & tbit(MI355Q_TYPE_IQ4_NL)) != 0) ok = plan_stage<MI355Q_TYPE_IQ4_NL>(st, c); break;
+            case MI355Q_TYPE_IQ4_XS: if constexpr ((SET & tbit(MI355Q_TYPE_IQ4_XS)) != 0) ok = plan_stage<MI355Q_TYPE_IQ4_XS>(st, c); break;
             default: break;
             }
         } else if (kind == PLAN_K_ATTN) {
@@ -937,7 +942,9 @@ static const void * plan_kernel(unsigned set) {
     if ((set & ~SET_K46) == 0)  return (const void *) k_plan<SET_K46>;
     if ((set & ~SET_K456) == 0) return (const void *) k_plan<SET_K456>;
     if ((set & ~SET_80) == 0)   return (const void *) k_plan<SET_80>;
-    return (const void *) k_plan<SET_ALL>;
+    if ((set & ~SET_ALL) == 0)  return (const void *) k_plan<SET_ALL>;
+    if ((set & ~SET_IQ4) == 0)  return (const void *) k_plan<SET_IQ4>;
+    return nullptr;                                            // (a mix of the IQ4 types with Q4_K / Q8_0 / Q4_0: no instantiation)
 }
 
 #ifdef MI355Q_STAMPS
@@ -1061,13 +1068,16 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
         if (in.y_kind != MI355Q_Y_ROWS && !paired) { mi355q_set_error("plan_create: unknown y_kind"); return MI355Q_ERR_UNSUPPORTED; }
         VecSrc x0, x1;
         if (!resolve(in.x, in.k, in.x_id, x0) || !resolve(in.x1, in.k, in.x1_id, x1)) { mi355q_set_error("plan_create: an activation operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
+        // the matrices of a stage share ONE quantized image of the activations: their types must pair with the same activation format
+        for (int i = 1; i < in.n_mats; ++i)
+            if (gemv_fast_family(in.mats[i].type) != gemv_fast_family(in.mats[0].type)) { mi355q_set_error("plan_create: the matrices of a stage must share the activation format (Q8_K or Q8_0 family)"); return MI355Q_ERR_UNSUPPORTED; }
         bool done[GEMV_MAX_MATS] = { false, false, false, false };
         bool first = true;
         for (int i = 0; i < in.n_mats; ++i) {
             if (done[i]) continue;
             const int type = in.mats[i].type;
             const int fam = gemv_fast_family(type);
-            if (fam < 0 || !(tbit(type) & SET_ALL) || !mi355q_weights_are_planar(type, in.k)) { mi355q_set_error("plan_create: weight type / k has no planar streaming kernel in the plan"); return MI355Q_ERR_UNSUPPORTED; }
+            if (fam < 0 || !(tbit(type) & SET_ANY) || !mi355q_weights_are_planar(type, in.k)) { mi355q_set_error("plan_create: weight type / k has no planar streaming kernel in the plan"); return MI355Q_ERR_UNSUPPORTED; }
             PlanStage p = {};
             p.kind = PLAN_K_GEMV; p.tag_off = (unsigned) v.size() + 1;
             int64_t rows = 0; int n = 0;
@@ -1126,6 +1136,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
     pl->even = (flags & MI355Q_FLAG_ROUND_EVEN) ? 1 : 0;
     pl->gran_count = gran_count + 2;
     const void * kern = plan_kernel(set);
+    if (!kern) { delete pl; mi355q_set_error("plan_create: this mix of weight types has no kernel instantiation"); return MI355Q_ERR_UNSUPPORTED; }
     int per_cu = 0;
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GEMV_THREADS, lds_total) != hipSuccess || per_cu < 1) {

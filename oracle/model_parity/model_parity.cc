@@ -44,7 +44,8 @@
 #include "ggml-alloc.h"
 #include "ggml-backend.h"
 
-struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; int n_expert = 0, n_used = 0; bool last_only = false; };
+struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; int n_expert = 0, n_used = 0; bool last_only = false;
+              ggml_type wtype = GGML_TYPE_Q4_K, wtype_more = GGML_TYPE_Q6_K; };      // the recipe's main type and its "more bits" type (--wtype)
 
 struct Layer { ggml_tensor *attn_norm, *ffn_norm, *wq, *wk, *wv, *wo, *wgate, *wup, *wdown, *kc, *vc, *gate_inp; };   // MoE: wgate / wup / wdown are [k, m, n_expert]
 struct Model {
@@ -71,14 +72,14 @@ static Model make_model(const Dims & d, const std::vector<ggml_backend_t> & back
             const bool mb = more_bits(il, d.n_layer);
             L.attn_norm = ggml_new_tensor_1d(c, GGML_TYPE_F32, d.n_embd);
             L.ffn_norm  = ggml_new_tensor_1d(c, GGML_TYPE_F32, d.n_embd);
-            L.wq = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_embd);
-            L.wk = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, n_embd_kv);
-            L.wv = ggml_new_tensor_2d(c, mb ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K, d.n_embd, n_embd_kv);
-            L.wo = ggml_new_tensor_2d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_embd);
+            L.wq = ggml_new_tensor_2d(c, d.wtype, d.n_embd, d.n_embd);
+            L.wk = ggml_new_tensor_2d(c, d.wtype, d.n_embd, n_embd_kv);
+            L.wv = ggml_new_tensor_2d(c, mb ? d.wtype_more : d.wtype, d.n_embd, n_embd_kv);
+            L.wo = ggml_new_tensor_2d(c, d.wtype, d.n_embd, d.n_embd);
             const int64_t ne = d.n_expert > 0 ? d.n_expert : 1;
-            L.wgate = ggml_new_tensor_3d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_ff, ne);
-            L.wup   = ggml_new_tensor_3d(c, GGML_TYPE_Q4_K, d.n_embd, d.n_ff, ne);
-            L.wdown = ggml_new_tensor_3d(c, mb ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K, d.n_ff, d.n_embd, ne);
+            L.wgate = ggml_new_tensor_3d(c, d.wtype, d.n_embd, d.n_ff, ne);
+            L.wup   = ggml_new_tensor_3d(c, d.wtype, d.n_embd, d.n_ff, ne);
+            L.wdown = ggml_new_tensor_3d(c, mb ? d.wtype_more : d.wtype, d.n_ff, d.n_embd, ne);
             L.gate_inp = d.n_expert > 0 ? ggml_new_tensor_2d(c, GGML_TYPE_F32, d.n_embd, d.n_expert) : nullptr;
             L.kc = ggml_new_tensor_1d(ckv, GGML_TYPE_F16, (int64_t) n_embd_kv * d.n_ctx);
             L.vc = ggml_new_tensor_1d(ckv, GGML_TYPE_F16, (int64_t) n_embd_kv * d.n_ctx);
@@ -207,6 +208,10 @@ int main(int argc, char ** argv) {
         if (a == "--preset") preset = next(); else if (a == "--layers") d.n_layer = atoi(next().c_str()); else if (a == "--vocab") d.n_vocab = atoi(next().c_str());
         else if (a == "--tokens") tokens = atoi(next().c_str()); else if (a == "--prompt") prompt = atoi(next().c_str()); else if (a == "--devs") devs = next();
         else if (a == "--fa") d.fa = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--noise") noise = next(); else if (a == "--bench") bench = atoi(next().c_str()); else if (a == "--pp") pp = atoi(next().c_str());
+        else if (a == "--wtype") { const std::string v = next();            // q4_k_m (default), iq4_xs (IQ4_XS + Q5_K), iq4_nl (IQ4_NL + Q5_K), q8_0, q5_k_m (Q5_K + Q6_K), q3_k (Q3_K + Q5_K)
+            if (v == "iq4_xs") { d.wtype = GGML_TYPE_IQ4_XS; d.wtype_more = GGML_TYPE_Q5_K; } else if (v == "iq4_nl") { d.wtype = GGML_TYPE_IQ4_NL; d.wtype_more = GGML_TYPE_Q5_K; }
+            else if (v == "q8_0") { d.wtype = d.wtype_more = GGML_TYPE_Q8_0; } else if (v == "q5_k_m") { d.wtype = GGML_TYPE_Q5_K; d.wtype_more = GGML_TYPE_Q6_K; }
+            else if (v == "q3_k") { d.wtype = GGML_TYPE_Q3_K; d.wtype_more = GGML_TYPE_Q5_K; } else if (v != "q4_k_m") { fprintf(stderr, "unknown --wtype %s\n", v.c_str()); return 3; } }
         else if (a == "--sched") use_sched = true; else if (a == "--no-cpu") no_cpu = true; else if (a == "--time-cpu") time_cpu = true;
         else if (a == "--moe") { const std::string v = next(); d.n_expert = atoi(v.c_str()); d.n_used = v.find(',') == std::string::npos ? 2 : atoi(v.c_str() + v.find(',') + 1); }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 3; }
@@ -271,7 +276,7 @@ int main(int argc, char ** argv) {
             static std::vector<uint8_t> cache[7][2];
             std::vector<uint8_t> fresh;
             const bool share = d.n_embd >= 4096;
-            std::vector<uint8_t> & q = share ? cache[w.slot][w.t->type == GGML_TYPE_Q6_K] : fresh;
+            std::vector<uint8_t> & q = share ? cache[w.slot][w.t->type == d.wtype_more] : fresh;
             if (q.empty()) {
                 std::vector<float> f((size_t) w.k * w.m);
                 if (share) { uint64_t sst = 88172645463325252ull + (uint64_t) w.slot; const float sc = 1.7320508f / sqrtf((float) w.k);      // uniform, variance 1/k (xorshift64)

@@ -637,6 +637,42 @@ def test_plan_llama_layer_mixed_types(G, torch, orc):
     plan.close()
 
 
+def test_plan_iq4_model_layer(G, torch, orc):
+    """An IQ4_XS-recipe layer (llama-quant.cpp: IQ4_XS for most tensors, IQ4_NL where a row is not a multiple of 256 blocks' worth, Q5_K attn_v,
+    Q6_K output-style matrix) as one persistent launch: the plan has a kernel instantiation for {IQ4_XS, IQ4_NL, Q5_K, Q6_K}; every stage equals the
+    per-matmul launch bit for bit and the oracle within tolerance.  A mix of the IQ4 types with Q4_K has no instantiation and is refused."""
+    rng = np.random.default_rng(78)
+    E, F, KV = 2048, 2816, 264
+    def W(t, m, k):
+        h = quantized_weights(t, m, k, rng)
+        return h, G.QWeight.from_host(t, h, m, k)
+    layer = [[W(oracle.IQ4_XS, E, E), W(oracle.IQ4_XS, KV, E), W(oracle.Q5_K, KV, E)], [W(oracle.IQ4_NL, E, E)],
+             [W(oracle.IQ4_XS, F, E), W(oracle.IQ4_XS, F, E)], [W(oracle.Q6_K, E, 4096)]]
+    stages, checks = [], []
+    for gi, grp in enumerate(layer):
+        k = grp[0][1].K
+        x = torch.from_numpy(rng.standard_normal((1, k)).astype(np.float32)).cuda()
+        ys = [torch.zeros((1, w.M), dtype=torch.float32, device="cuda") for _, w in grp]
+        stages.append(([w for _, w in grp], x, ys, gi > 0))
+        checks.append((grp, x, ys))
+    plan = G.Plan(stages)
+    for _ in range(2):
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        for grp, x, ys in checks:
+            for (h, w), y in zip(grp, ys):
+                assert np.array_equal(_bits_t(y), _bits_t(G.mul_mat(w, x)))
+                check_close(y.cpu().numpy(), orc.mul_mat(w.type, h, x.cpu().numpy(), w.M, 1, w.K))
+    plan.close()
+    x = torch.zeros((1, E), dtype=torch.float32, device="cuda")
+    (_, wn), (_, w5) = W(oracle.IQ4_NL, 64, E), W(oracle.Q5_K, 64, E)          # Q8_0-family and Q8_K-family matrices cannot share a stage's image
+    with pytest.raises(G.Mi355qError):
+        G.Plan([([wn, w5], x, [torch.zeros((1, 64), device="cuda"), torch.zeros((1, 64), device="cuda")], False)])
+    (_, wa), (_, wb) = W(oracle.IQ4_XS, 64, E), W(oracle.Q4_K, 64, E)
+    with pytest.raises(G.Mi355qError):
+        G.Plan([([wa], x, [torch.zeros((1, 64), device="cuda")], False), ([wb], x, [torch.zeros((1, 64), device="cuda")], False)])
+
+
 def test_plan_rejects_what_it_cannot_stream(G, torch):
     rng = np.random.default_rng(5)
     w = G.QWeight.from_host(oracle.Q3_K, random_blocks(oracle.Q3_K, 32, 256, rng), 32, 256)      # no planar streamer for Q3_K

@@ -283,6 +283,27 @@ def test_whole_model_decode_equal_to_cpu(mode):
 
 @pytest.mark.gpu
 @needs_plugin
+@pytest.mark.parametrize("wtype,planned", [("iq4_xs", True), ("iq4_nl", None), ("q5_k_m", True), ("q8_0", True), ("q3_k", False)])
+def test_whole_model_other_weight_recipes(wtype, planned):
+    """The same model with other quantization recipes against the CPU backend run live (prompt step + 10 decode steps): IQ4_XS / IQ4_NL (+ Q5_K,
+    Q6_K output), Q5_K_M, Q8_0 decode as ONE persistent launch per token (the plan has kernel instantiations for these type sets); the IQ4_NL
+    recipe puts a Q8_0-family type and a Q8_K-family type (Q5_K attn_v) on the same activations, which one stage cannot serve -- whether its plan
+    is accepted is not asserted; Q3_K has no streaming kernel, so its decode graphs run node by node -- resident all the same (0 nodes refused),
+    with the batched canonical tier at the prompt step."""
+    if _model_parity() is None or not _model_parity().exists():
+        pytest.skip("oracle/_ref/*/model_parity not built")
+    r = _run_model(["--preset", "small", "--layers", "3", "--vocab", "8192", "--prompt", "40", "--tokens", "10", "--wtype", wtype])
+    print(r.stdout[-2500:], r.stderr[-600:])
+    m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ARGMAX DIFFERS" not in r.stdout and "0 refused by MI355_0" in r.stdout
+    n_planned, _ = _planned(r.stderr)
+    if planned is not None:
+        assert n_planned == (10 if planned else 0), (wtype, n_planned)
+
+
+@pytest.mark.gpu
+@needs_plugin
 def test_whole_model_two_devices_through_the_scheduler():
     """--split-mode layer as llama.cpp does it: ONE process, ggml_backend_sched over two devices of the plugin (the one card of the test box presented
     twice, MI355_DUP_DEVICES=2) + the CPU backend.  The scheduler cuts the 4-layer model in two splits; the boundary activation travels through the
