@@ -283,12 +283,12 @@ def test_whole_model_decode_equal_to_cpu(mode):
 
 @pytest.mark.gpu
 @needs_plugin
-@pytest.mark.parametrize("wtype,planned", [("iq4_xs", True), ("iq4_nl", None), ("q5_k_m", True), ("q8_0", True), ("q3_k", False)])
+@pytest.mark.parametrize("wtype,planned", [("iq4_xs", True), ("iq4_nl", True), ("q5_k_m", True), ("q8_0", True), ("q3_k", False)])
 def test_whole_model_other_weight_recipes(wtype, planned):
     """The same model with other quantization recipes against the CPU backend run live (prompt step + 10 decode steps): IQ4_XS / IQ4_NL (+ Q5_K,
     Q6_K output), Q5_K_M, Q8_0 decode as ONE persistent launch per token (the plan has kernel instantiations for these type sets); the IQ4_NL
-    recipe puts a Q8_0-family type and a Q8_K-family type (Q5_K attn_v) on the same activations, which one stage cannot serve -- whether its plan
-    is accepted is not asserted; Q3_K has no streaming kernel, so its decode graphs run node by node -- resident all the same (0 nodes refused),
+    recipe puts a Q8_0-family type and a Q8_K-family type (Q5_K attn_v) on the same activations: two stages with the same prologue, each
+    quantizing the vector in its own format; Q3_K has no streaming kernel, so its decode graphs run node by node -- resident all the same (0 nodes refused),
     with the batched canonical tier at the prompt step."""
     if _model_parity() is None or not _model_parity().exists():
         pytest.skip("oracle/_ref/*/model_parity not built")
