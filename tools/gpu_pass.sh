@@ -1,7 +1,8 @@
+# scratch driver for one gpurun call (rewritten per experiment); default: the GPU test suite
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests/test_plugin.py -m gpu -x -q > gpurun_out/gpu_tests_plugin.log 2>&1; rc=$?
-tail -3 gpurun_out/gpu_tests_plugin.log | cut -c1-300
-[ $rc -ne 0 ] && { tail -70 gpurun_out/gpu_tests_plugin.log | cut -c1-300; exit 1; }
+timeout -k 10 1150 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1; rc=$?
+tail -5 gpurun_out/gpu_tests_full.log | cut -c1-300
+[ $rc -ne 0 ] && { tail -80 gpurun_out/gpu_tests_full.log | cut -c1-300; exit 1; }
 exit 0
