@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_API_VERSION 2
+#define MI355Q_API_VERSION 3
 
 /* error codes */
 #define MI355Q_OK                0
@@ -274,6 +274,10 @@ typedef struct mi355q_stage {
      * build_ffn (LLM_FFN_SILU + LLM_FFN_PAR) folded into the producer, so that ffn_down gathers one vector instead of two.  Every workgroup
      * computes matching rows of both matrices; same f32 expressions as mi355q_op_unary_mul.                                                   */
     int          y_kind, y_unary;
+    /* --- API version 3 --- */
+    float       *x_out;      /* X_NORM / X_UNARY_MUL: optional; the activation vector the prologue forms (rms_norm(.) * w, unary(.) * x1) is ALSO
+                              * stored here as plain f32 -- for a caller whose graph hands that vector to somebody besides this stage's matrices
+                              * (llama.cpp: result_norm is read back as the embeddings; a LoRA branch multiplies it again).  One workgroup stores it. */
 } mi355q_stage;
 #define MI355Q_Y_ROWS      0
 #define MI355Q_Y_UNARY_MUL 1
@@ -281,6 +285,10 @@ typedef struct mi355q_plan mi355q_plan;
 int     mi355q_plan_create(mi355q_plan **out, const mi355q_stage *stages, int n_stages, int flags);
 int     mi355q_plan_run(mi355q_plan *plan, void *stream);
 int     mi355q_plan_status(mi355q_plan *plan);
+/* test hook: set the plan's run counter (the source of the granule tags' epoch); a value near the 32-bit wrap exercises the granule reset */
+int     mi355q_plan_debug_set_runs(mi355q_plan *plan, unsigned long long runs);
+/* diagnostics of an aborted plan: its 32 sync words (0: abort flag; 1..7: kind of the wait that gave up, stage, workgroup, wave, two operands, landed pages) */
+int     mi355q_plan_debug_words(mi355q_plan *plan, unsigned *out32);
 /* asynchronous form: enqueues a 4-byte device-to-host copy of the plan's abort word into *host_flag (pinned memory recommended) on `stream`;
  * after the stream has been synchronized, *host_flag != 0 means a poll of an earlier run timed out.                                       */
 int     mi355q_plan_status_async(mi355q_plan *plan, unsigned *host_flag, void *stream);

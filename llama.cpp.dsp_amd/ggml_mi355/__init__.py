@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "mi355q_quantize_act",
     "mi355q_mul_mat_workspace", "mi355q_mul_mat", "mi355q_mul_mat_multi",
     "mi355q_mul_mat_id_workspace", "mi355q_mul_mat_id",
-    "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_status_async", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
+    "mi355q_plan_create", "mi355q_plan_run", "mi355q_plan_status", "mi355q_plan_status_async", "mi355q_plan_debug_set_runs", "mi355q_plan_debug_words", "mi355q_plan_weight_bytes", "mi355q_plan_launch_stages",
     "mi355q_plan_destroy",
     "mi355q_op_bin_bcast", "mi355q_op_unary", "mi355q_op_rms_norm", "mi355q_op_cpy", "mi355q_op_soft_max",
     "mi355q_op_rope", "mi355q_op_mul_mat_f", "mi355q_op_get_rows", "mi355q_op_scale", "mi355q_op_cpy_indirect", "mi355q_op_argsort", "mi355q_op_sum_rows",
@@ -89,7 +89,7 @@ class _Stage(C.Structure):         # mi355q_stage
     _fields_ = [("mats", _Mat * 4), ("n_mats", C.c_int), ("flags", C.c_int), ("x", C.c_void_p), ("k", C.c_int64),
                 ("kind", C.c_int), ("x_kind", C.c_int), ("x_unary", C.c_int), ("eps", C.c_float),
                 ("x1", C.c_void_p), ("norm_w", C.c_void_p), ("sum_out", C.c_void_p), ("attn", C.POINTER(_Attn)),
-                ("y_id", C.c_int64 * 4), ("sum_id", C.c_int64), ("x_id", C.c_int64), ("x1_id", C.c_int64), ("y_kind", C.c_int), ("y_unary", C.c_int)]
+                ("y_id", C.c_int64 * 4), ("sum_id", C.c_int64), ("x_id", C.c_int64), ("x1_id", C.c_int64), ("y_kind", C.c_int), ("y_unary", C.c_int), ("x_out", C.c_void_p)]
 
 
 STAGE_DEPENDS, STAGE_NO_PLAIN = 0x1, 0x2
@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
     L.mi355q_plan_create.argtypes = [C.POINTER(vp), C.POINTER(_Stage), i32, i32]
     L.mi355q_plan_run.argtypes = [vp, vp]
     L.mi355q_plan_status.argtypes = [vp]
+    L.mi355q_plan_debug_set_runs.argtypes = [vp, C.c_ulonglong]
+    L.mi355q_plan_debug_words.argtypes = [vp, C.POINTER(C.c_uint)]
     L.mi355q_plan_destroy.argtypes = [vp]
     L.mi355q_plan_weight_bytes.restype = i64; L.mi355q_plan_weight_bytes.argtypes = [vp]
     L.mi355q_plan_launch_stages.argtypes = [vp]
@@ -338,10 +340,10 @@ class Plan:
                 if isinstance(sd, dict):
                     ws_, x, ys = sd["ws"], sd["x"], sd["ys"]
                     st.x_kind = sd.get("x_kind", X_PLAIN); st.x_unary = sd.get("unary", UNARY_SILU); st.eps = float(sd.get("eps", 0.0))
-                    st.x1 = ptr(sd.get("x1")); st.norm_w = ptr(sd.get("norm_w")); st.sum_out = ptr(sd.get("sum_out"))
+                    st.x1 = ptr(sd.get("x1")); st.norm_w = ptr(sd.get("norm_w")); st.sum_out = ptr(sd.get("sum_out")); st.x_out = ptr(sd.get("x_out"))
                     st.flags = STAGE_NO_PLAIN if sd.get("no_plain") else 0
                     st.y_kind = sd.get("y_kind", Y_ROWS); st.y_unary = sd.get("y_unary", UNARY_SILU)
-                    for t in (sd.get("x1"), sd.get("norm_w"), sd.get("sum_out")):
+                    for t in (sd.get("x1"), sd.get("norm_w"), sd.get("sum_out"), sd.get("x_out")):
                         assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x.shape[-1])
                 else:
                     ws_, x, ys, depends = sd
@@ -371,7 +373,16 @@ class Plan:
         _check(lib().mi355q_plan_run(self._h, _stream(_torch())), "plan_run")
 
     def status(self) -> int:
-        return int(lib().mi355q_plan_status(self._h))
+        st = int(lib().mi355q_plan_status(self._h))
+        if st != 0:
+            w = (C.c_uint * 32)()
+            lib().mi355q_plan_debug_words(self._h, w)
+            print("mi355q plan aborted: sync words", [hex(x) for x in w], file=sys.stderr)
+        return st
+
+    def debug_set_runs(self, runs: int):
+        """Test hook: set the run counter the granule tags' epoch derives from (near 2**32 / (stages + 1) the next run resets the granules)."""
+        _check(lib().mi355q_plan_debug_set_runs(self._h, C.c_ulonglong(runs)), "plan_debug_set_runs")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(G):
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert declared == set(G.ABI_SYMBOLS), declared ^ set(G.ABI_SYMBOLS)
-    assert L.mi355q_api_version() == 2
+    assert L.mi355q_api_version() == 3
 
 
 def test_geometry_matches_oracle(G, orc):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel timeline of the decode plan (diagnostic build libmi355q_dbg.so; dev tool, GPU box only).
-Per stage and workgroup, waves 0 and 15 stamp  GEMV: 0 entry, 5 descriptor fields arrived, 1 primed, 2 operands gathered (producers polled), 6 all waves gathered (barrier passed), 7 this wave's spans quantized, 3 activations quantized in LDS (barrier passed), 4 rows done;
+Per stage and workgroup, consumer waves 0 and 14 stamp  GEMV: 0 entry, 2 operands gathered (producers polled), 6 all waves gathered (barrier passed), 7 this wave's spans quantized, 3 activations quantized in LDS (barrier passed), 1 this wave's first row has landed, 4 rows done; 5 = the LOADER (wave 15) has requested the stage's last page;
 ATTN: 0 entry, 1 q/k/v gathered, 2 roped + stored, 3 scores, 4 softmax, 5 P.V published;  COMBINE: 0 entry, 2 merged.
 Usage: MI355Q_LIB=.../libmi355q_dbg.so python tools/planstamps.py [--layers 2] [--pos 100]"""
 import argparse, ctypes, sys
@@ -23,7 +23,7 @@ act = torch.randn((1, cfg["n_embd"]), dtype=torch.float32, device=dev)
 plan = stage.make_decode_plan(cfg, act, 128, False)
 n = plan.launch_stages
 grid = 256
-buf = torch.zeros(n * grid * 2 * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(n * grid * 2 * 8 + n * grid * 8, dtype=torch.int64, device=dev)
 L.mi355q_debug_set_plan_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 stage.set_token(a.pos)
 for _ in range(3):
@@ -32,15 +32,22 @@ torch.cuda.synchronize()
 assert L.mi355q_debug_set_plan_stamps(buf.data_ptr(), n) == 0
 plan.run(); torch.cuda.synchronize()
 assert plan.status() == 0
-s = buf.cpu().numpy().reshape(n, grid, 2, 8).astype(np.float64)
+raw = buf.cpu().numpy()
+prof = raw[n * grid * 16:].reshape(n, grid, 8).astype(np.float64)
+s = raw[:n * grid * 16].reshape(n, grid, 2, 8).astype(np.float64)
 t0 = s[0, :, :, 0][s[0, :, :, 0] > 0].min()
 s = np.where(s > 0, (s - t0) / 100.0, np.nan)          # us
-print(f"{n} launch stages; times in us since the first stage entry; per stamp: min / median / max over workgroups (wave 0 | median wave 15)")
+print(f"{n} launch stages; times in us since the first stage entry; per stamp: min / median / max over workgroups (wave 0 | median wave 14)")
 for st in range(n):
     line = [f"stage {st:3d}"]
-    for i in (0, 5, 1, 2, 6, 7, 3, 4):
+    for i in (5, 0, 2, 6, 7, 3, 1, 4):
         c0, c1 = s[st, :, 0, i], s[st, :, 1, i]
         if np.all(np.isnan(c0)):
             continue
         line.append(f"[{i}] {np.nanmin(c0):7.2f}/{np.nanmedian(c0):7.2f}/{np.nanmax(c0):7.2f} | {np.nanmedian(c1):7.2f}")
     print("  ".join(line))
+
+print("step-loop cycle sums of wave 0 per stage (median over workgroups, shader cycles): bookkeeping | try next | arithmetic + term + arrive | row close | wait for next")
+for st in range(n):
+    if prof[st].sum() > 0:
+        print(f"stage {st:3d}  " + "  ".join(f"{np.median(prof[st, :, i]):9.0f}" for i in range(5)))
