@@ -5,32 +5,22 @@
 //
 //   GEMV    up to 4 planar weight matrices of one type against one activation vector x.  The prologue forms x in LDS --
 //           x0 | rms_norm(x0 + x1) * w | unary(x0) * x1, quantized exactly as the CPU does (act_quant.cuh) -- then the
-//           workgroup multiplies its rows; arithmetic per row is gemv_fast.hip's (gemv_stream.cuh is shared): bit-identical.
+//           workgroup streams its rows; arithmetic per row is gemv_fast.hip's (gemv_stream.cuh is shared): bit-identical.
 //   ATTN    rope(q), rope(k), this token's K / V cache stores and causal attention of the one token over the f16 cache,
 //           one workgroup per (head, KV split); COMBINE merges the splits of a head (log-sum-exp).
 //
-// Round 3: the WEIGHT STREAM IS DECOUPLED FROM THE DEPENDENCY CHAIN.  Wave 15 of every workgroup is a LOADER: it walks the
-// stage list on its own and copies the workgroup's weight rows of every GEMV stage, in stage order, from HBM into a ring of
-// 1-KiB pages in LDS (~110-140 KiB per CU) with LDS-DMA (global_load_lds_dwordx4, saddr form, nt, up to four pages per M0
-// write, 32 instructions in flight) -- weights depend on nothing the launch computes, so it never waits for an activation,
-// only for ring space.  Waves 0..14 are CONSUMERS: they poll the stage's operands, build the quantized image, then take the
-// rows that are (or soon will be) resident in the ring: wait for "landed" to cover the row, ds_read_b128 it, same consumers
-// as gemv_fast.hip, publish.  While the consumers sit in a hand-off (4-6 us in round 2, during which HBM idled) the loader
-// fills the ring with the next stages' rows, ~30 MB chip-wide; the round-2 kernel held 8 KiB of registers per wave and could
-// not run ahead of the stage it was in (profiles/round2_plan_timeline.md; the measured data path alone: tools/micro/ring_stream.hip,
-// 6.5-6.8 TB/s against 6.9 TB/s for a plain 16-wave stream).
-//
-//   * handshake in LDS words, no hardware barrier after the first one: the loader publishes the count of pages that have
-//     LANDED (vmcnt retires in order: after s_waitcnt vmcnt(32) everything but the last 32 pages is in LDS); every consumer
-//     wave keeps a HEAD word = the first page it still needs, the loader fills while fill - min(head) < ring pages.  The
-//     loader takes no part in s_barrier, so the consumers synchronize among themselves through an LDS counter.
-//   * DATAFLOW between stages, not barriers: a value produced during the run is published element by element as an 8-byte
+//   * DATAFLOW, not barriers.  A value produced during the run is published element by element as an 8-byte
 //     {f32 value, u32 tag} GRANULE (one naturally aligned agent-scope store; tag = launch epoch + producing stage) in a
 //     plan-private buffer; a consumer polls exactly the granules it needs with agent-scope (sc1) loads until every tag
-//     matches (MI355X_MICROARCH.md, hand-off price list: the data-tagged granule is the cheapest cross-CU edge).
+//     matches.  No counter, no flag, no release/acquire fence, no store acknowledgement: the hand-off is the data
+//     (MI355X_MICROARCH.md, hand-off price list: a data-tagged granule is the cheapest cross-CU edge; a flag/barrier
+//     protocol costs 1.7-2.5x).  Round 1's two-level grid barrier + separate activation fetch cost 8-9 us per dependent
+//     step; see DESIGN.md section 5.6 for the measured chain now.
+//   * the weight stream does not stop at a dependency: a wave requests the first chunks of its rows of stage s+1 as soon
+//     as it has finished stage s, BEFORE it polls for the activations.
 //   * no re-arming: tags grow monotonically over launches (the host re-zeroes the granules before the 32-bit epoch wraps).
-//   * every wait has a wall-clock bound (s_memrealtime): on timeout the workgroup raises the plan's sticky abort flag and
-//     leaves, so the grid always drains (one workgroup per CU: all are resident unless another persistent kernel holds CUs).
+//   * every poll has a wall-clock bound (s_memrealtime): on timeout the workgroup raises the plan's sticky abort flag and
+//     returns, so the grid always drains (one workgroup per CU: all are resident unless another persistent kernel holds CUs).
 //
 // Bound: HBM read of W.  Algorithmic bytes per launch = sum over stages, matrices of m * row_size(type, k) (+ the KV cache
 // window of ATTN stages: 2 * n_kv * n_head_kv * head_dim * 2 bytes).
@@ -42,23 +32,13 @@
 
 namespace mi355q {
 
-constexpr int PLAN_NC   = GEMV_WAVES - 1;         // consumer waves; wave PLAN_NC is the loader
-constexpr int PLAN_CT   = PLAN_NC * WAVE;         // consumer threads
-constexpr int PLAN_DMA  = 32;                     // LDS-DMA instructions in flight (ring_stream.hip: 32 beats 48: what is in flight is not yet usable)
-constexpr int PLAN_MAXS = 8;                      // 256-element spans of the activation vector per consumer wave: k <= 8 * 15 * 256
-enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32 };
+constexpr int PLAN_D_MAX = 8;                     // ring depth (1-KiB steps in flight per wave)
+__host__ __device__ constexpr int plan_depth(int type) {   // Q5_K / Q6_K slots carry qh too (1.5 KiB per step): 6 steps are the bytes of 8 Q4_K steps
+    return (type == MI355Q_TYPE_Q5_K || type == MI355Q_TYPE_Q6_K) ? 6 : PLAN_D_MAX;
+}
+enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32, PLAN_F_DIRECT = 64 };
 enum { PLAN_K_GEMV = 0, PLAN_K_ATTN = 1, PLAN_K_COMBINE = 2 };
 enum { PLAN_SYNC_ABORT = 0, PLAN_SYNC_WORDS = 32 };
-// LDS control block (byte offsets): health flag, landed page count, consumer barrier counter, per-wave head words, f64 partials of the norm
-enum { CB_OK = 0, CB_LANDED = 4, CB_BAR = 8, CB_HEAD = 64, CB_PART = 128,
-       CB_GEN = 256,                              // row-slot generations: two sets of 32 words (GEMV stages alternate)
-       CB_CNT = 512,                              // row-slot arrival counters (32 words): the wave whose arrival completes a row closes it
-       CB_PCNT = 768,                             // PAIRED stages: arrivals of a pair's two dot products (64 words)
-       CB_PDV = 1024,                             // PAIRED stages: the two dot products of a pair (2 x 64 words)
-       CB_STATE = 1536,                           // (diagnostic build) one word per wave: where it is
-       CB_BYTES = 1600 };
-constexpr int PLAN_TERM_STEPS = 64;               // steps whose per-lane terms fit the term buffer (64 x 256 bytes behind the control block)
-constexpr int PLAN_TERM_BYTES = PLAN_TERM_STEPS * 256;
 
 typedef unsigned long long Granule;               // low dword: f32 value bits, high dword: tag
 
@@ -82,23 +62,22 @@ struct AttnStage {
 };
 
 struct alignas(64) PlanStage {
-    // -- line 0: everything the LOADER needs (one 64-byte scalar load) --
-    const uint8_t * w[GEMV_MAX_MATS];             // rows of a matrix are contiguous (stride == row_bytes: checked at creation)
-    int             row_begin[GEMV_MAX_MATS];     // first concatenated row of each matrix (unused entries: INT_MAX)
-    int             total_rows, rows_per_wg, row_bytes;
-    int             kf;                           // kind | flags << 8 | glog << 24
-    // -- the consumers' part --
+    // -- what the streamers need per row, contiguous (arrives with a few scalar loads issued together) --
+    const uint8_t * w[GEMV_MAX_MATS];
+    int64_t         w_stride[GEMV_MAX_MATS];
     float *         y[GEMV_MAX_MATS];
     Granule *       yg;                           // granules of the stage's outputs, indexed by CONCATENATED row
-    int             k, n_mats, type, flags;
-    int             kind, glog, x_kind, x_unary;
+    int             row_begin[GEMV_MAX_MATS];     // first concatenated row of each matrix (unused entries: INT_MAX)
+    int             total_rows, rows_per_wg, k, n_mats;
+    // -- the rest --
+    int             type, flags, prime, kind;
     VecSrc          x0, x1;
     const float *   norm_w;
     Granule *       sum_gran; float * sum_plain; float * x_out;
     const AttnStage * attn;
-    float           eps; unsigned tag_off;
+    const AttnStage * next_attn;                  // the attention descriptor of the NEXT stage (prefetched with it), or null
+    float           eps; int x_kind, x_unary; unsigned tag_off;
 };
-static_assert(sizeof(PlanStage) == 256, "PlanStage is four 64-byte lines");
 typedef const __attribute__((address_space(4))) PlanStage * StageC;   // descriptors are read with scalar loads
 
 // type sets a kernel instantiation can stream (register allocation is the max over the set)
@@ -111,296 +90,143 @@ constexpr unsigned SET_ALL  = SET_K456 | SET_80;
 constexpr unsigned SET_IQ4  = tbit(MI355Q_TYPE_IQ4_XS) | tbit(MI355Q_TYPE_IQ4_NL) | tbit(MI355Q_TYPE_Q5_K) | tbit(MI355Q_TYPE_Q6_K);
 constexpr unsigned SET_ANY  = SET_ALL | SET_IQ4;
 
+struct PlanCursor { int gr, s; const uint8_t * row; };
+
 #ifdef MI355Q_STAMPS
-// Diagnostic build only (libmi355q_dbg.so): waves 0 and 14 of every workgroup record 100 MHz wall-clock stamps per stage:
-// g_plan_stamps[((stage*grid + wg)*2 + (wave==14))*8 + i].  The product library contains none of this.
+// Diagnostic build only (libmi355q_dbg.so): waves 0 and 15 of every workgroup record 100 MHz wall-clock stamps per stage:
+// g_plan_stamps[((stage*grid + wg)*2 + (wave==15))*8 + i].  The product library contains none of this.
 __device__ unsigned long long * g_plan_stamps = nullptr;
 __device__ int g_plan_stamp_stages = 0;
-#define PLAN_STAMP(i) do { if (g_plan_stamps && lane == 0 && (wave == 0 || wave == PLAN_NC - 1) && c.stage < g_plan_stamp_stages) \
+#define PLAN_STAMP(i) do { if (g_plan_stamps && lane == 0 && (wave == 0 || wave == GEMV_WAVES - 1) && c.stage < g_plan_stamp_stages) \
     g_plan_stamps[(((size_t) c.stage * c.grid + blockIdx.x) * 2 + (wave ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-// per-phase cycle sums of the step loop (wave 0 of every workgroup): g_plan_stamps + n_stages * grid * 16 + (stage * grid + wg) * 8 + i
-// where every consumer wave is (dumped into the plan's sync words 8..23 by the wave that gives up): CB_PART + 128 + 4 * wave
-#define PLAN_STATE(code) do { if (lane == 0) cb_st(c.cb + CB_STATE + 4u * (threadIdx.x >> 6), ((unsigned) c.stage << 24) | (unsigned) (code)); } while (0)
-#define PLAN_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[6] = { 0, 0, 0, 0, 0, 0 }
-#define PLAN_PROF(i) do { const unsigned long long prof_n = __builtin_amdgcn_s_memtime(); prof_acc[i] += prof_n - prof_t; prof_t = prof_n; } while (0)
-#define PLAN_PROF_FLUSH do { if (g_plan_stamps && lane == 0 && wave == 0 && c.stage < g_plan_stamp_stages) for (int pi = 0; pi < 6; ++pi) \
-    g_plan_stamps[(size_t) g_plan_stamp_stages * c.grid * 16 + ((size_t) c.stage * c.grid + blockIdx.x) * 8 + pi] = prof_acc[pi]; } while (0)
 #else
 #define PLAN_STAMP(i) do { } while (0)
-#define PLAN_STATE(code) do { } while (0)
-#define PLAN_PROF_DECL do { } while (0)
-#define PLAN_PROF(i) do { } while (0)
-#define PLAN_PROF_FLUSH do { } while (0)
 #endif
 
-// ---- wave-uniform values, said so: the compiler keeps loop-carried state in SGPRs only while it can prove every branch around it uniform;
-// values read back from LDS or from a lane are uniform by construction here, and readfirstlane tells it
-__device__ __forceinline__ int      ufl(int x)       { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ unsigned uflu(unsigned x) { return (unsigned) __builtin_amdgcn_readfirstlane((int) x); }
-template <typename P> __device__ __forceinline__ P uniform_ptr(P p) {
-    const unsigned long long v = (unsigned long long) (uintptr_t) p;
-    const unsigned lo = uflu((unsigned) v), hi = uflu((unsigned) (v >> 32));
-    return (P) (uintptr_t) (((unsigned long long) hi << 32) | lo);
-}
-
-// ---- the control words live in LDS and are touched with explicit DS instructions on their LDS byte address (a `volatile` generic pointer
-// compiles to flat accesses with sc0 sc1 and a vmcnt(0) wait behind each, which would drain the loader's DMA queue at every publish)
-__device__ __forceinline__ void     cb_st(unsigned addr, unsigned v)  { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
-__device__ __forceinline__ void     cb_add(unsigned addr, unsigned v) { asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
-// lane 0 counts an arrival on an LDS word that wraps to 0 after `limit` (ds_inc: old >= limit ? 0 : old + 1); every lane gets the OLD value
-__device__ __forceinline__ unsigned cb_arrive(unsigned addr, unsigned limit, int lane) {
-    unsigned old = 0;
-    if (lane == 0) asm volatile("ds_inc_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(limit) : "memory");
-    return (unsigned) __builtin_amdgcn_readlane((int) old, 0);
-}
-__device__ __forceinline__ unsigned cb_ld(unsigned addr) { unsigned v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory"); return uflu(v); }
-
-// what a wave needs to know about the launch
-struct Ctx {
-    uint8_t * lds; unsigned cb, ctl_off;          // LDS base (generic pointer to the kernel's LDS symbol) and the control block's LDS byte address
-    unsigned ring_off, ring_bytes, ring_magic, np, np_magic;   // the ring: byte offset inside lds, size, floor(2^32 / size), pages, floor(2^32 / pages)
-    unsigned * sync; unsigned long long timeout;
-    unsigned grid, epoch; int even, stage;
+// A wave's own copy of the per-matrix fields of a stage descriptor, in SGPRs: read once per stage with independent
+// scalar loads (one round trip).  Reading them per row instead (matrix index -> base -> stride: a dependent chain of
+// scalar loads) costs microseconds whenever the descriptors miss the scalar cache.
+struct StageW {
+    const uint8_t * w0, * w1, * w2, * w3; int64_t ws0, ws1, ws2, ws3; float * y0, * y1, * y2, * y3; Granule * g; int rb1, rb2, rb3; int paired;
+    __device__ __forceinline__ void load(StageC st) {          // what the loader needs (live through the prologue)
+        paired = 0;
+        w0 = st->w[0]; w1 = st->w[1]; w2 = st->w[2]; w3 = st->w[3];
+        ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = st->w_stride[2]; ws3 = st->w_stride[3];
+        rb1 = st->row_begin[1]; rb2 = st->row_begin[2]; rb3 = st->row_begin[3];
+    }
+    // PAIRED stage (y = unary(W0 x) * (W1 x)): this workgroup's LOCAL row 2 q is row p0 + q of matrix 0, local row 2 q + 1 the same row of matrix 1.
+    // A wave takes pairs q = wave, wave + 16, ... and streams the two rows of a pair back to back (plan_next_row), so it holds both dot products
+    // itself and publishes unary(.) * (.) without a trip through LDS.
+    __device__ __forceinline__ void load_paired(StageC st, int p0, int np) {
+        paired = 1;
+        ws0 = st->w_stride[0]; ws1 = st->w_stride[1]; ws2 = ws3 = 0;
+        w0 = st->w[0] + (int64_t) p0 * ws0; w1 = st->w[1] + (int64_t) p0 * ws1; w2 = w3 = nullptr;
+        rb1 = np; rb2 = rb3 = 0x7FFFFFFF;
+    }
+    __device__ __forceinline__ void load_out(StageC st) {      // what the consumer needs (read after the prologue)
+        y0 = st->y[0]; y1 = st->y[1]; y2 = st->y[2]; y3 = st->y[3]; g = st->yg;
+    }
+    // all fields are read BEFORE the selects (a select between field addresses would keep the struct in scratch memory)
+    __device__ __forceinline__ const uint8_t * row_ptr(int r) const {
+        const uint64_t a0 = (uint64_t) w0, a1 = (uint64_t) w1, a2 = (uint64_t) w2, a3 = (uint64_t) w3;
+        const int64_t s0 = ws0, s1 = ws1, s2 = ws2, s3 = ws3;
+        const int b1 = rb1, b2 = rb2, b3 = rb3;
+        if (paired) return (const uint8_t *) (((r & 1) ? a1 : a0) + (uint64_t) ((int64_t) (r >> 1) * ((r & 1) ? s1 : s0)));
+        const int mi = (r >= b1) + (r >= b2) + (r >= b3);      // row_begin is ascending
+        const uint64_t w = mi == 0 ? a0 : mi == 1 ? a1 : mi == 2 ? a2 : a3;
+        const int64_t ws = mi == 0 ? s0 : mi == 1 ? s1 : mi == 2 ? s2 : s3;
+        const int rb = mi == 0 ? 0 : mi == 1 ? b1 : mi == 2 ? b2 : b3;
+        return (const uint8_t *) (w + (uint64_t) ((int64_t) (r - rb) * ws));
+    }
+    __device__ __forceinline__ float * y_ptr(int r) const {
+        const uint64_t a0 = (uint64_t) y0, a1 = (uint64_t) y1, a2 = (uint64_t) y2, a3 = (uint64_t) y3;
+        const int b1 = rb1, b2 = rb2, b3 = rb3;
+        const int mi = (r >= b1) + (r >= b2) + (r >= b3);
+        const uint64_t y = mi == 0 ? a0 : mi == 1 ? a1 : mi == 2 ? a2 : a3;
+        const int rb = mi == 0 ? 0 : mi == 1 ? b1 : mi == 2 ? b2 : b3;
+        return (float *) y + (r - rb);
+    }
 };
 
-// x mod ring_bytes for a stream byte position (< 2^32): q = mulhi(x, floor(2^32 / d)) is the quotient or one less
-__device__ __forceinline__ unsigned ring_pos(const Ctx & c, unsigned x) {
-    unsigned r = x - __umulhi(x, c.ring_magic) * c.ring_bytes;
-    if (r >= c.ring_bytes) r -= c.ring_bytes;
-    return r;
+struct StageGeom { int r_hi, nb, nchunks, steps; };
+template <int T> __device__ __forceinline__ StageGeom plan_geom(int k, int r_hi) {
+    StageGeom g;
+    g.r_hi = r_hi;
+    g.nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? k >> 5 : k >> 8;
+    g.nchunks = row_chunks(T, k); g.steps = (g.nchunks + 63) >> 6;
+    return g;
 }
 
-struct PollCtx { unsigned * sync; unsigned long long timeout, t0; int stage; };
-// false = give up (timeout or the plan's abort flag is up)
-__device__ __forceinline__ bool poll_backoff(const PollCtx & pc, unsigned & spins, int lane) {
-    __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 63u) == 0u) {
-        unsigned ab = 0;
-        if (lane == 0) ab = __hip_atomic_load(pc.sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ab = uflu(ab);
-        if (ab != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - pc.t0 > pc.timeout) {
-            if (lane == 0 && __hip_atomic_exchange(pc.sync + PLAN_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { pc.sync[1] = 7u /* a producer poll */; pc.sync[2] = (unsigned) pc.stage; pc.sync[3] = blockIdx.x; pc.sync[4] = threadIdx.x >> 6; }
-            return false;
-        }
+// the row a wave takes after local row r: rows are dealt round robin; a PAIRED stage deals PAIRS (rows 2q, 2q+1 back to back, then 16 pairs on)
+__device__ __forceinline__ int plan_next_row(int r, int paired) { return r + (paired ? ((r & 1) ? 2 * GEMV_WAVES - 1 : 1) : GEMV_WAVES); }
+
+template <int T>
+__device__ __forceinline__ void plan_issue(Chunk & slot, PlanCursor & ld, const StageW & st, const StageGeom & g, int lane) {
+    if (ld.gr < g.r_hi) {                                     // wave-uniform
+        if (64 * ld.s + lane < g.nchunks) chunk_load<T>(slot, ld.row, g.nb, ld.s, lane);
+        if (++ld.s == g.steps) { ld.s = 0; ld.gr = plan_next_row(ld.gr, st.paired); if (ld.gr < g.r_hi) ld.row = st.row_ptr(ld.gr); }
     }
-    return true;
-}
-// one more round of a wait on an LDS word of this workgroup (landed pages, barrier arrivals, slot generations): false = the workgroup is dead (another
-// wave gave up) or the wait has lasted ~2^18 polls (tens of milliseconds): the plan's abort word is raised and everybody leaves
-// (`why`, `a`, `b`: what was waited for -- kept in the plan's sync words 1..7 by the first wave that gives up: mi355q_plan_debug_words)
-enum { WHY_LANDED = 1, WHY_SLOT = 2, WHY_COUNT = 3, WHY_PAIR = 4, WHY_BARRIER = 5, WHY_RING = 6 };
-__device__ __forceinline__ void plan_give_up(const Ctx & c, int lane, unsigned why, unsigned a, unsigned b) {
-    if (lane == 0) {
-        cb_st(c.cb + CB_OK, 0u);
-        if (__hip_atomic_exchange(c.sync + PLAN_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            c.sync[1] = why; c.sync[2] = (unsigned) c.stage; c.sync[3] = blockIdx.x; c.sync[4] = threadIdx.x >> 6; c.sync[5] = a; c.sync[6] = b;
-            c.sync[7] = cb_ld(c.cb + CB_LANDED);
-#ifdef MI355Q_STAMPS
-            for (int i = 0; i < 16; ++i) c.sync[8 + i] = cb_ld(c.cb + CB_STATE + 4u * (unsigned) i);
-            for (int i = 0; i < 8; ++i) c.sync[24 + i] = cb_ld(c.cb + CB_HEAD + 4u * (unsigned) (2 * i));
-#endif
-        }
-    }
-}
-__device__ __forceinline__ bool lds_spin(const Ctx & c, unsigned & spins, int lane, unsigned why, unsigned a, unsigned b) {
-    __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 255u) == 0u) {
-        if (cb_ld(c.cb + CB_OK) == 0u) return false;
-        if (spins > (1u << 16)) { plan_give_up(c, lane, why, a, b); return false; }
-    }
-    return true;
 }
 
-// barrier among the 15 consumer waves (the loader never joins one): arrive on an LDS counter, spin until all have.  Every consumer wave calls it
-// the same number of times.  An arriving wave's earlier LDS writes are complete (lgkmcnt) before its arrival is counted.
-// Per-wave progress that changes from stage to stage: kept OUT of Ctx (a Ctx handed to a function by mutable reference makes the compiler forget
-// that c.lds is the kernel's LDS symbol, and every LDS access becomes a flat one).
-struct Prog { int gemv_idx;         // GEMV stages done (every wave counts the same)
-              unsigned base_page;    // stream position (BYTES since the launch began) at which the current stage's rows start
-              unsigned bar_target; };  // consumer barrier: arrivals expected at the next cbar()
-__device__ __forceinline__ bool cbar(const Ctx & c, Prog & pr, int lane) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) cb_add(c.cb + CB_BAR, 1u);
-    pr.bar_target += (unsigned) PLAN_NC;
-    unsigned spins = 0;
-    while ((int) (cb_ld(c.cb + CB_BAR) - pr.bar_target) < 0) if (!lds_spin(c, spins, lane, WHY_BARRIER, pr.bar_target, 0)) return false;
-    return cb_ld(c.cb + CB_OK) != 0u;
+// request slots [from, to) of the ring for stage st (its loader cursor continues where it stands)
+template <int T, int D>
+__device__ __forceinline__ void plan_fill(Chunk (&ring)[D], int from, int to, PlanCursor & ld, const StageW & st, const StageGeom & g, int lane) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d >= from && d < to) plan_issue<T>(ring[d], ld, st, g, lane);
 }
 
 __device__ __forceinline__ void publish(Granule * gp, float v, unsigned tag) {
     __hip_atomic_store(gp, ((Granule) tag << 32) | (Granule) __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- stage geometry: where the rows of a workgroup sit in the stream ----------------------------------------------------------------
-// The stream of a workgroup is TIGHTLY PACKED: stream row q of a stage (q = 0, 1, ...) occupies bytes [q * row_bytes, (q + 1) * row_bytes) behind the
-// stage's first byte, and a stage begins where the previous one ended -- no alignment anywhere (row_bytes is a multiple of 16), so a consumer finds
-// a row with one multiplication.  Which row of which matrix stream row q is:
-//   plain stage   concatenated row r_lo + q of the workgroup's range [r_lo, r_hi)
-//   PAIRED stage  (y = unary(W0 x) * (W1 x): a pair's two rows must meet) pairs in groups of G = 2^glog: the G rows of matrix 0, then the same G
-//                 rows of matrix 1, group after group -- a pair's second row is at most 2 G rows behind its first one, and the loader still copies
-//                 runs of G contiguous rows
-// The loader copies SEGMENTS (contiguous byte ranges of one matrix) back to back; a ring page may hold the end of one and the start of the next.
-__device__ __forceinline__ void stage_rows(StageC st, int & r_lo, int & r_hi) {
-    const int rpw = st->rows_per_wg, total = st->total_rows;
-    r_lo = (int) blockIdx.x * rpw; r_hi = min(r_lo + rpw, total);
-    if (r_lo > r_hi) r_lo = r_hi;
-}
-__device__ __forceinline__ unsigned stage_stream_bytes(StageC st) {
-    int r_lo, r_hi; stage_rows(st, r_lo, r_hi);
-    return (unsigned) (r_hi - r_lo) * ((st->flags & PLAN_F_PAIRED) ? 2u : 1u) * (unsigned) st->row_bytes;
-}
+__device__ __forceinline__ float unary_f(int uop, float x);
 
-// ---- the loader ------------------------------------------------------------------------------------------------------------------------
-// K consecutive 1-KiB pages with ONE M0 write: the instruction offset advances the global and the LDS address alike.  M0 is written inside the
-// statement that uses it (cdna_hip_programming.md 5.7); the source base is wave-uniform (SGPR pair: saddr form, no address VALU at all).
-template <int K> __device__ __forceinline__ void dma_pages(const uint8_t * g_in, unsigned voff, unsigned lds_addr_in) {
-    const uint8_t * g = uniform_ptr(g_in); const unsigned lds_addr = uflu(lds_addr_in);
-    if constexpr (K == 1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(voff), "s"(g), "s"(lds_addr) : "memory");
-    if constexpr (K == 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 nt" :: "v"(voff), "s"(g), "s"(lds_addr) : "memory");
-    if constexpr (K == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 nt\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048 nt" :: "v"(voff), "s"(g), "s"(lds_addr) : "memory");
-    if constexpr (K == 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 nt\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048 nt\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072 nt" :: "v"(voff), "s"(g), "s"(lds_addr) : "memory");
-}
-
-// pos: stream bytes requested so far (since the launch began); tail: the first page a consumer still needs; landed: pages published as resident
-struct Loader { unsigned pos, tail, landed, spins; bool dead; };
-
-__device__ __forceinline__ void loader_tail(Loader & L, const Ctx & c, int lane) {     // min over the consumers' head words (word 15 stays 0xFFFFFFFF)
-    unsigned h;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(c.cb + CB_HEAD + 4u * (unsigned) (lane & 15)) : "memory");
-    h = min(h, (unsigned) dpp_i<0xB1>((int) h)); h = min(h, (unsigned) dpp_i<0x4E>((int) h)); h = min(h, (unsigned) dpp_i<0x141>((int) h)); h = min(h, (unsigned) dpp_i<0x140>((int) h));
-    L.tail = uflu(h);
-}
-__device__ __forceinline__ void loader_publish(Loader & L, const Ctx & c, unsigned landed, int lane) {
-    if ((int) (landed - L.landed) > 0) { L.landed = landed; if (lane == 0) cb_st(c.cb + CB_LANDED, landed); }
-}
-// copy one segment (bytes % 16 == 0) to the stream position where the previous one ended
-__device__ __forceinline__ void loader_segment(Loader & L, const Ctx & c, const uint8_t * g_in, unsigned bytes_in, int lane) {
-    const uint8_t * g = uniform_ptr(g_in);
-    const unsigned bytes = uflu(bytes_in);
-    const unsigned voff = 16u * (unsigned) lane;
-    unsigned done = 0;
-    while (done < bytes && !L.dead) {
-        L.pos = uflu(L.pos); L.tail = uflu(L.tail); L.landed = uflu(L.landed); L.spins = uflu(L.spins); done = uflu(done);
-        const unsigned page = L.pos >> 10, inpage = L.pos & 1023u, left = bytes - done;
-        // pages of the ring this request may use: [page, tail + np)   (a consumer's head may be AHEAD of pos: a wave that waits for rows not yet requested)
-        auto room = [&]() { const int used = (int) (page - L.tail); return (int) c.np - (used > 0 ? used : 0); };
-        int space = room();
-        if (space < 8) { loader_tail(L, c, lane); space = room(); }
-        if (space <= 0) {                                        // the ring is full: let everything in flight land and be seen (the consumers need it to free pages), look again
-            if (L.landed != page) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); loader_publish(L, c, page, lane); }
-            __builtin_amdgcn_s_sleep(1);
-            if ((++L.spins & 1023u) == 0u) {
-                if (cb_ld(c.cb + CB_OK) == 0u) L.dead = true;
-                else if (L.spins > (1u << 20)) { plan_give_up(c, lane, WHY_RING, page, L.tail); L.dead = true; }     // ~ a fraction of a second of polling
-            }
-            continue;
-        }
-        L.spins = 0;
-        unsigned rpage = page - __umulhi(page, c.np_magic) * c.np; if (rpage >= c.np) rpage -= c.np;      // page % np
-        const unsigned dst = (unsigned) (size_t) c.lds + c.ring_off + rpage * 1024u;        // (low 32 bits of a shared-memory pointer = its LDS byte address)
-        const uint8_t * src = g + done;
-        if (inpage != 0u || left < 1024u) {                      // part of a page: lanes [inpage / 16, (inpage + n) / 16) copy src .. src + n
-            const unsigned n = min(1024u - inpage, left);
-            const unsigned l0 = inpage >> 4, l1 = (inpage + n) >> 4;
-            if ((unsigned) lane >= l0 && (unsigned) lane < l1) dma_pages<1>(src - inpage, voff, dst);
-            done += n; L.pos += n;
-        } else {
-            unsigned k = min(min(4u, left >> 10), min((unsigned) space, c.np - rpage));
-            k = uflu(k);
-            if (k == 4u)      dma_pages<4>(src, voff, dst);
-            else if (k == 3u) dma_pages<3>(src, voff, dst);
-            else if (k == 2u) dma_pages<2>(src, voff, dst);
-            else              dma_pages<1>(src, voff, dst);
-            done += k << 10; L.pos += k << 10;
-        }
-        // at most PLAN_DMA instructions (each touches one page, pages in rising order, landing in issue order) are still in flight: every page
-        // before the last PLAN_DMA completely requested ones has landed
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PLAN_DMA) : "memory");
-        if ((L.pos >> 10) > (unsigned) PLAN_DMA) loader_publish(L, c, (L.pos >> 10) - (unsigned) PLAN_DMA, lane);
-    }
-}
-
-static __device__ __forceinline__ void plan_loader(StageC stages, int n_stages, const Ctx & c) {
-    const int lane = lane_id();
-    __builtin_amdgcn_s_setprio(3);
-    Loader L; L.pos = 0; L.tail = 0; L.landed = 0; L.spins = 0; L.dead = false;
-#pragma unroll 1
-    for (int s = 0; s < n_stages && !L.dead; ++s) {
-        StageC st = stages + s;
-        const int kf = st->kf;
-        // touch the descriptor's other lines (and the attention descriptor of an ATTN stage): the consumers' scalar loads then hit this XCD's L2 /
-        // the scalar cache instead of paying an HBM miss at the head of each of the ~200 stages of a token
-        { const int t1 = st->k, t2 = st->x_kind; const float e = st->eps; asm volatile("" :: "s"(t1), "s"(t2), "s"(e));
-          if ((kf & 0xFF) != PLAN_K_GEMV) { const __attribute__((address_space(4))) AttnStage * a = (const __attribute__((address_space(4))) AttnStage *) st->attn;
-                                            const int u1 = a->n_head, u2 = a->mask_f16; const float u3 = a->corr1; asm volatile("" :: "s"(u1), "s"(u2), "s"(u3)); } }
-        if ((kf & 0xFF) != PLAN_K_GEMV) continue;
-        const unsigned rb = (unsigned) st->row_bytes;
-        int r_lo, r_hi; stage_rows(st, r_lo, r_hi);
-        const uint8_t * w0 = st->w[0], * w1 = st->w[1], * w2 = st->w[2], * w3 = st->w[3];
-        if ((kf >> 8) & PLAN_F_PAIRED) {
-            const int np = r_hi - r_lo, G = 1 << ((kf >> 24) & 0xFF);
-#pragma unroll 1
-            for (int g0 = 0; g0 < np; g0 += G) {
-                const int n_g = min(G, np - g0);
-                const size_t off = (size_t) (r_lo + g0) * rb;
-                loader_segment(L, c, w0 + off, (unsigned) n_g * rb, lane);
-                loader_segment(L, c, w1 + off, (unsigned) n_g * rb, lane);
-            }
-        } else {
-            const int mb[GEMV_MAX_MATS + 1] = { 0, st->row_begin[1], st->row_begin[2], st->row_begin[3], 0x7FFFFFFF };
-            const uint8_t * ws[GEMV_MAX_MATS] = { w0, w1, w2, w3 };
+// consume this wave's rows of the stage; slot d holds item d, d+D, ... ; refills keep D items in flight
+template <int T, int D>
+__device__ __forceinline__ void plan_run(Chunk (&ring)[D], PlanCursor & ld, const StageW & st, const StageGeom & g, int r_lo, int wave, int lane,
+                                         const ActView * av, unsigned tag, bool plain, int pair_p0, int pair_unary) {
+    // the consumers' lane-invariant state (LDS offsets, shifts) is derived from an opaque copy of the lane id HERE, so
+    // that it cannot be computed (and kept live, and spilled) before the prologue
+    int lane_c = lane; asm volatile("" : "+v"(lane_c));
+    int cs_gr = r_lo + (st.paired ? 2 * wave : wave), cs_s = 0;
+    float acc[1] = { 0.0f };
+    float first_of_pair = 0.0f;                              // PAIRED: the dot product of the pair's matrix-0 row, until the matrix-1 row is done
+    while (cs_gr < g.r_hi) {
 #pragma unroll
-            for (int i = 0; i < GEMV_MAX_MATS; ++i) {
-                const int lo = max(r_lo, mb[i]), hi = min(r_hi, mb[i + 1]);
-                if (hi > lo) loader_segment(L, c, ws[i] + (size_t) (lo - mb[i]) * rb, (unsigned) (hi - lo) * rb, lane);
+        for (int d = 0; d < D; ++d) {
+            if (cs_gr < g.r_hi) {                             // wave-uniform
+                if (64 * cs_s + lane_c < g.nchunks) Consume<T, 1>::run(ring[d], cs_s, lane_c, av, acc);
+                if (++cs_s == g.steps) {                      // row finished: reduce, publish (one granule), next row
+                    const float t = wave_sum(acc[0]);
+                    if (st.paired) {                           // (wave-uniform)
+                        if (!(cs_gr & 1)) first_of_pair = t;
+                        else if (lane_c == 0) {
+                            const float r = __fmul_rn(unary_f(pair_unary, first_of_pair), t);
+                            publish(st.g + pair_p0 + (cs_gr >> 1), r, tag);
+                            if (plain) st.y0[pair_p0 + (cs_gr >> 1)] = r;
+                        }
+                    } else if (lane_c == 0) { publish(st.g + cs_gr, t, tag); if (plain) *st.y_ptr(cs_gr) = t; }
+                    acc[0] = 0.0f; cs_s = 0; cs_gr = plan_next_row(cs_gr, st.paired);
+                }
+                plan_issue<T>(ring[d], ld, st, g, lane);      // refill the slot just consumed
             }
         }
-#ifdef MI355Q_STAMPS
-        if (g_plan_stamps && lane == 0 && s < g_plan_stamp_stages) g_plan_stamps[(((size_t) s * c.grid + blockIdx.x) * 2) * 8 + 5] = __builtin_amdgcn_s_memrealtime();   // the loader has requested this stage's last byte
-#endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    loader_publish(L, c, (L.pos + 1023u) >> 10, lane);           // (the stream's last page may be partly filled: it is complete as far as there is data)
 }
 
-// ---- the consumers' view of a resident row -------------------------------------------------------------------------------------------------
-// `row` = LDS address of the row's first byte; WRAP: the row runs over the ring's end (rare: its bytes behind the end continue at the ring's start;
-// ring size and wrap point are multiples of 1024 and every field offset a multiple of its size, so no single read straddles)
-struct RowView { const uint8_t * ring; unsigned off, ring_bytes; };
-template <typename V, bool WRAP> __device__ __forceinline__ V ring_ld(const RowView & r, unsigned x) {
-    unsigned a = r.off + x;
-    if constexpr (WRAP) { if (a >= r.ring_bytes) a -= r.ring_bytes; }
-    return *(const V *) (r.ring + a);
-}
-// chunk_load<T> of gemv_stream.cuh with the planar row in LDS: same fields, same lanes
-template <int T, bool W> __device__ __forceinline__ void chunk_lds(Chunk & ch, const RowView & r, int nb, int s, int lane) {
-    ch.q = ring_ld<uint4, W>(r, 1024 * s + 16 * lane);
-    if constexpr (T == MI355Q_TYPE_Q4_K) ch.a = ring_ld<uint4, W>(r, 128 * nb + 128 * s + 16 * (lane >> 3));
-    if constexpr (T == MI355Q_TYPE_Q5_K) { ch.b = ring_ld<uint4, W>(r, 128 * nb + 256 * s + (32 * (lane >> 3) + 16 * (lane & 1))); ch.a = ring_ld<uint4, W>(r, 160 * nb + 128 * s + 16 * (lane >> 3)); }
-    if constexpr (T == MI355Q_TYPE_Q6_K) {
-        const int j = lane & 7;
-        ch.a  = ring_ld<uint4, W>(r, 128 * nb + 512 * s + (64 * (lane >> 3) + 32 * (j >> 2) + 16 * (j & 1)));
-        ch.sc = ring_ld<uint16_t, W>(r, 192 * nb + 128 * s + 2 * lane);
-        ch.dh = ring_ld<uint16_t, W>(r, 208 * nb + 16 * s + 2 * (lane >> 3));
-    }
-    if constexpr (T == MI355Q_TYPE_Q8_0) ch.dh = ring_ld<uint16_t, W>(r, 32 * nb + 64 * s + 2 * (lane >> 1));
-    if constexpr (T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ch.dh = ring_ld<uint16_t, W>(r, 16 * nb + 128 * s + 2 * lane);
-    if constexpr (T == MI355Q_TYPE_IQ4_XS) { const uint2 h = ring_ld<uint2, W>(r, 128 * nb + 64 * s + 8 * (lane >> 3)); ch.a.x = h.x; ch.a.y = h.y; }
-}
-
-struct RowGeom { int nb, nchunks, steps; };
-template <int T> __device__ __forceinline__ RowGeom row_geom(int k) {
-    RowGeom g;
-    g.nb = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? k >> 5 : k >> 8;
-    g.nchunks = row_chunks(T, k); g.steps = (g.nchunks + 63) >> 6;
-    return g;
+// LDS visibility + workgroup barrier WITHOUT draining vmcnt: __syncthreads() fences every address space and so waits
+// for the weight loads in flight; these fences name the LDS only (lgkmcnt), and -- unlike a bare s_barrier, which is
+// IntrNoMem for the compiler -- they also keep the LDS accesses on their side of the barrier at compile time.
+__device__ __forceinline__ void plan_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // ---- operand gather ------------------------------------------------------------------------------------------------
-// A SPAN is 256 consecutive elements of a vector; lane l owns elements 256 sp + 4l .. 4l+3.  Granules: two 16-byte agent-scope (sc1) buffer
-// loads per lane = {v0, tag0, v1, tag1}, {v2, tag2, v3, tag3}; plain vectors: one 16-byte load.  Lanes beyond the vector read zeros (the buffer
-// resource bounds the access) and are excluded from the tag check.
+// A CHUNK is 128 consecutive elements of a vector; lane l owns elements 128c + 2l, +1.  Granules: one 16-byte agent-scope
+// (sc1) buffer load per lane = {v0, tag0, v1, tag1}; plain vectors: one 8-byte load.  Lanes beyond the vector read zeros
+// (the buffer resource bounds the access) and are excluded from the tag check.
 typedef unsigned int plan_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int plan_u2 __attribute__((ext_vector_type(2)));
 struct SrcView { __amdgpu_buffer_rsrc_t rs; unsigned expect; int tagged; };
@@ -412,7 +238,7 @@ __device__ __forceinline__ SrcView src_view(const VecSrc & v, int first, int n, 
     else          s.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (v.plain + first), 0, n * 4, 0x00020000);
     return s;
 }
-// one attempt at two elements (attention operands): returns the values and whether they are valid (tags match)
+// one attempt: returns the two values and whether they are valid (tags match)
 __device__ __forceinline__ bool src_try(const SrcView & s, int chunk, int lane, float & a0, float & a1) {
     if (s.tagged) {
         const plan_u4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, chunk * 1024 + 16 * lane, 0, 16 /* sc1 */);
@@ -423,16 +249,21 @@ __device__ __forceinline__ bool src_try(const SrcView & s, int chunk, int lane, 
     a0 = __uint_as_float(v.x); a1 = __uint_as_float(v.y);
     return true;
 }
-// one attempt at a lane's four elements of span sp
-__device__ __forceinline__ bool span_try(const SrcView & s, int sp, int lane, float4 & v) {
-    if (s.tagged) {
-        const plan_u4 a = __builtin_amdgcn_raw_buffer_load_b128(s.rs, sp * 2048 + 32 * lane, 0, 16 /* sc1 */);
-        const plan_u4 b = __builtin_amdgcn_raw_buffer_load_b128(s.rs, sp * 2048 + 32 * lane + 16, 0, 16);
-        v = make_float4(__uint_as_float(a.x), __uint_as_float(a.z), __uint_as_float(b.x), __uint_as_float(b.z));
-        return a.y == s.expect && a.w == s.expect && b.y == s.expect && b.w == s.expect;
+
+struct PollCtx { unsigned * sync; unsigned long long timeout, t0; };
+// false = give up (timeout or the plan's abort flag is up)
+__device__ __forceinline__ bool poll_backoff(const PollCtx & pc, unsigned & spins, int lane) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) == 0u) {
+        unsigned ab = 0;
+        if (lane == 0) ab = __hip_atomic_load(pc.sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab = (unsigned) __builtin_amdgcn_readfirstlane((int) ab);
+        if (ab != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - pc.t0 > pc.timeout) {
+            if (lane == 0) __hip_atomic_store(pc.sync + PLAN_SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
     }
-    const plan_u4 a = __builtin_amdgcn_raw_buffer_load_b128(s.rs, sp * 1024 + 16 * lane, 0, 0);
-    v = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
     return true;
 }
 
@@ -468,17 +299,42 @@ __device__ __forceinline__ float unary_f(int uop, float x) {          // ops_glu
     return __fdiv_rn(1.0f, 1.0f + expf(-x));
 }
 
-template <int FAM>
-__device__ __forceinline__ void plan_quantize_span(const float4 v, int span, uint8_t * lds, int k, bool even, int lane) {
-    if constexpr (FAM == FAM_Q8K) quantize_span_to_lds<FAM_Q8K, false>(v, span, lds, k, lane);
-    else if (even)                quantize_span_to_lds<FAM_Q80, true>(v, span, lds, k, lane);
-    else                          quantize_span_to_lds<FAM_Q80, false>(v, span, lds, k, lane);
+// A pointer / value that is wave-uniform by construction but arrives in VGPRs (arguments of a non-inlined function): moved to SGPRs so that
+// everything read through it becomes scalar loads instead of per-lane global loads with their ~1 us dependent latencies.
+template <typename P> __device__ __forceinline__ P uniform_ptr(P p) {
+    const unsigned long long v = (unsigned long long) (uintptr_t) p;
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v), hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    return (P) (uintptr_t) (((unsigned long long) hi << 32) | lo);
 }
 
-// Gather the stage's activation vector t[k] into REGISTERS: span wave + 15 i -> t[i].  PLAIN t = x0, NORM t = x0 (+ x1), UNARY_MUL t = unary(x0) * x1.
-// Four spans (up to sixteen 16-byte loads per lane) are in flight per poll.  NORM: returns this wave's partial sum of squares in `ssq`; the
-// workgroup stage % grid also publishes t (the next residual's operand).  false = the poll gave up.
-__device__ __forceinline__ bool plan_gather(StageC st, const Ctx & c, int k, int wave, int lane, float4 (&t)[PLAN_MAXS], double & ssq) {
+struct StageCtx {
+    uint8_t * lds; float * stg; int * ctl; double * part; unsigned * sync; unsigned long long timeout;
+    unsigned grid, epoch; int even, stage, image;     // image: bytes of the activation image at the start of the LDS allocation
+    const uint8_t * next_desc, * next_attn; unsigned pre_lds;   // the next stage's descriptors (global) and a 1-KiB LDS scratch area their lines are DMA-ed into
+};
+
+// Warm this XCD's L2 with the NEXT stage's descriptor while the current stage runs: descriptors are cold after every launch boundary and a
+// scalar load that misses to HBM costs ~1-2 us at the head of each of the ~200 stages of a token.  16 bytes per lane, global -> LDS with no VGPR
+// destination (the data is never read from there); untracked by the compiler's vmcnt bookkeeping, which can only make its waits longer.
+__device__ __forceinline__ void plan_prefetch_desc(const StageCtx & c, int wave, int lane) {
+    static_assert(sizeof(PlanStage) <= 32 * 16 && sizeof(AttnStage) <= 32 * 16, "descriptor prefetch covers 512 bytes each");
+    if (wave == GEMV_WAVES - 1 && c.next_desc != nullptr) {
+        const bool second = lane >= 32;                        // lanes 0..31: the stage descriptor; lanes 32..63: its attention descriptor, if any
+        const uint8_t * base = second ? c.next_attn : c.next_desc;
+        const int n16 = second ? (int) ((sizeof(AttnStage) + 15) / 16) : (int) ((sizeof(PlanStage) + 15) / 16);
+        if (base != nullptr && (lane & 31) < n16) {
+            const uint8_t * g = base + 16 * (lane & 31);
+            const unsigned dst = (unsigned) __builtin_amdgcn_readfirstlane((int) c.pre_lds);     // (wave-uniform by construction; the asm needs an SGPR)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(dst) : "memory");
+        }
+    }
+}
+enum { CTL_OK = 0 };
+
+// Gather the stage's activation vector t[k] (f32) into the LDS staging area: PLAIN t = x0, NORM t = x0 (+ x1), UNARY_MUL
+// t = unary(x0) * x1.  Chunks are dealt round-robin to the waves, two in flight per wave.  NORM: returns this wave's partial
+// sum of squares in `ssq`; the workgroup `sum_wg` also publishes t (the next residual's operand).  false = poll gave up.
+__device__ __forceinline__ bool plan_gather(StageC st, const StageCtx & c, int k, int wave, int lane, double & ssq) {
     const int x_kind = st->x_kind, uop = st->x_unary & 0xFF;
     const bool two = st->x1.plain != nullptr || st->x1.gran != nullptr;
     VecSrc v0, v1;
@@ -488,106 +344,169 @@ __device__ __forceinline__ bool plan_gather(StageC st, const Ctx & c, int k, int
     const SrcView s1 = src_view(two ? v1 : v0, 0, k, c.epoch);
     const bool pub = (st->flags & PLAN_F_SUM) && blockIdx.x == (unsigned) c.stage % c.grid;
     const unsigned tag = c.epoch + st->tag_off;
-    const int spans = (k + 255) >> 8;
-    PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime(); pc.stage = c.stage;
+    const int chunks = (k + 127) >> 7;
+    PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
     ssq = 0.0;
-#pragma unroll
-    for (int r = 0; r < PLAN_MAXS; r += 4) {
-        if (wave + r * PLAN_NC >= spans) break;                 // (uniform)
-        float4 a[4], b[4];
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sp = wave + (r + i) * PLAN_NC;
-                a[i] = make_float4(0.f, 0.f, 0.f, 0.f); b[i] = a[i];
-                if (sp < spans) {                               // (uniform)
-                    const bool inside = 256 * sp + 4 * lane < k;
-                    ok = (span_try(s0, sp, lane, a[i]) || !inside) && ok;
-                    if (two) ok = (span_try(s1, sp, lane, b[i]) || !inside) && ok;
+    // four 16-byte loads per lane are in flight per poll: two chunks of both operands, or four chunks of a single operand
+    // (a chunk past the end reads zeros through the bounded buffer resource and is not checked)
+    auto emit = [&](int cc, float p0, float p1, float q0, float q1) {
+        const int e = 128 * cc + 2 * lane;
+        if (e < k) {                                           // (k is even)
+            float t0, t1;
+            if (x_kind == MI355Q_X_UNARY_MUL) { t0 = __fmul_rn(unary_f(uop, p0), q0); t1 = __fmul_rn(unary_f(uop, p1), q1); }
+            else if (two)                     { t0 = __fadd_rn(p0, q0); t1 = __fadd_rn(p1, q1); }
+            else                              { t0 = p0; t1 = p1; }
+            if (x_kind == MI355Q_X_NORM) {
+                ssq += (double) __fmul_rn(t0, t0); ssq += (double) __fmul_rn(t1, t1);      // (ggml_float)(x*x): the square is rounded to f32 first
+                if (pub) {
+                    publish(st->sum_gran + e, t0, tag); publish(st->sum_gran + e + 1, t1, tag);
+                    if (st->flags & PLAN_F_SUM_PLAIN) { st->sum_plain[e] = t0; st->sum_plain[e + 1] = t1; }
                 }
+            }
+            *(float2 *) (c.stg + e) = make_float2(t0, t1);
+        }
+    };
+    const int per_it = two ? 2 : 4;
+#pragma unroll 1
+    for (int ch = wave; ch < chunks; ch += per_it * GEMV_WAVES) {
+        float a0, a1, b0, b1, e0, e1, f0, f1;
+        const int c1 = ch + GEMV_WAVES, c2 = ch + 2 * GEMV_WAVES, c3 = ch + 3 * GEMV_WAVES;
+        for (;;) {
+            bool ok;
+            if (two) {
+                ok =       src_try(s0, ch, lane, a0, a1) || 128 * ch + 2 * lane >= k;
+                ok = (src_try(s1, ch, lane, b0, b1) || 128 * ch + 2 * lane >= k) && ok;
+                ok = (src_try(s0, c1, lane, e0, e1) || 128 * c1 + 2 * lane >= k) && ok;
+                ok = (src_try(s1, c1, lane, f0, f1) || 128 * c1 + 2 * lane >= k) && ok;
+            } else {
+                ok =       src_try(s0, ch, lane, a0, a1) || 128 * ch + 2 * lane >= k;
+                ok = (src_try(s0, c1, lane, b0, b1) || 128 * c1 + 2 * lane >= k) && ok;
+                ok = (src_try(s0, c2, lane, e0, e1) || 128 * c2 + 2 * lane >= k) && ok;
+                ok = (src_try(s0, c3, lane, f0, f1) || 128 * c3 + 2 * lane >= k) && ok;
             }
             if (__ballot(!ok) == 0ull) break;
             if (!poll_backoff(pc, spins, lane)) return false;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sp = wave + (r + i) * PLAN_NC;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int e = 256 * sp + 4 * lane;
-            if (sp < spans && e < k) {
-                if (x_kind == MI355Q_X_UNARY_MUL) { v.x = __fmul_rn(unary_f(uop, a[i].x), b[i].x); v.y = __fmul_rn(unary_f(uop, a[i].y), b[i].y); v.z = __fmul_rn(unary_f(uop, a[i].z), b[i].z); v.w = __fmul_rn(unary_f(uop, a[i].w), b[i].w); }
-                else if (two)                     { v.x = __fadd_rn(a[i].x, b[i].x); v.y = __fadd_rn(a[i].y, b[i].y); v.z = __fadd_rn(a[i].z, b[i].z); v.w = __fadd_rn(a[i].w, b[i].w); }
-                else                              v = a[i];
-                if (x_kind == MI355Q_X_NORM) {
-                    // (ggml_float)(x*x): the square is rounded to f32 first; element order inside a lane as the CPU's loop
-                    ssq += (double) __fmul_rn(v.x, v.x); ssq += (double) __fmul_rn(v.y, v.y); ssq += (double) __fmul_rn(v.z, v.z); ssq += (double) __fmul_rn(v.w, v.w);
-                    if (pub) {
-                        publish(st->sum_gran + e, v.x, tag); publish(st->sum_gran + e + 1, v.y, tag); publish(st->sum_gran + e + 2, v.z, tag); publish(st->sum_gran + e + 3, v.w, tag);
-                        if (st->flags & PLAN_F_SUM_PLAIN) *(float4 *) (st->sum_plain + e) = v;
-                    }
-                }
-            }
-            t[r + i] = v;
-        }
+        if (two) { emit(ch, a0, a1, b0, b1); emit(c1, e0, e1, f0, f1); }
+        else     { emit(ch, a0, a1, 0.f, 0.f); emit(c1, b0, b1, 0.f, 0.f); emit(c2, e0, e1, 0.f, 0.f); emit(c3, f0, f1, 0.f, 0.f); }
     }
     return true;
 }
 
-// One GEMV stage, start to finish, for weight type T (consumer waves):
-//   [gather x into registers (polls its producers) -> glue -> quantize x -> LDS image] -> the rows of this wave, as the loader lands them
+template <int FAM>
+__device__ __forceinline__ void plan_quantize_span(const float4 v, int span, uint8_t * lds, int k, bool even, int lane) {
+    if constexpr (FAM == FAM_Q8K) quantize_span_to_lds<FAM_Q8K, false>(v, span, lds, k, lane);
+    else if (even)                quantize_span_to_lds<FAM_Q80, true>(v, span, lds, k, lane);
+    else                          quantize_span_to_lds<FAM_Q80, false>(v, span, lds, k, lane);
+}
+
+// A stage whose activation vector is ONE vector taken as it is (X_PLAIN, no second operand: wo, ffn_down): a wave fetches whole 256-element
+// spans -- lane l the four elements 4l .. 4l+3, i.e. two 16-byte granule loads -- and quantizes each span into the LDS image straight from its
+// registers.  No staging copy and no workgroup barrier between gathering and quantizing (plan_gather needs one: its chunks are dealt 16 apart,
+// so a 256-block's two halves sit in different waves).  Two spans (four loads) are in flight per poll.  false = the poll gave up.
+template <int FAM>
+__device__ __forceinline__ bool plan_gather_direct(StageC st, const StageCtx & c, int k, int wave, int lane) {
+    VecSrc v0;
+    v0.plain = st->x0.plain; v0.gran = st->x0.gran; v0.tag_off = st->x0.tag_off; v0.pad = 0;
+    const SrcView s0 = src_view(v0, 0, k, c.epoch);
+    const int spans = k >> 8;                                  // (k % 256 == 0, checked at plan creation)
+    PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+#pragma unroll 1
+    for (int sp = wave; sp < spans; sp += 2 * GEMV_WAVES) {
+        const int sp2 = sp + GEMV_WAVES;
+        float4 va, vb;
+        for (;;) {
+            bool ok = true;
+            if (s0.tagged) {
+                const plan_u4 a0 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp * 2048 + 32 * lane, 0, 16 /* sc1 */);
+                const plan_u4 a1 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp * 2048 + 32 * lane + 16, 0, 16);
+                const plan_u4 b0 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp2 * 2048 + 32 * lane, 0, 16);      // (past the vector: zeros, not checked)
+                const plan_u4 b1 = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp2 * 2048 + 32 * lane + 16, 0, 16);
+                va = make_float4(__uint_as_float(a0.x), __uint_as_float(a0.z), __uint_as_float(a1.x), __uint_as_float(a1.z));
+                vb = make_float4(__uint_as_float(b0.x), __uint_as_float(b0.z), __uint_as_float(b1.x), __uint_as_float(b1.z));
+                ok = a0.y == s0.expect && a0.w == s0.expect && a1.y == s0.expect && a1.w == s0.expect;
+                if (sp2 < spans) ok = ok && b0.y == s0.expect && b0.w == s0.expect && b1.y == s0.expect && b1.w == s0.expect;
+            } else {
+                const plan_u4 a = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp * 1024 + 16 * lane, 0, 0);
+                const plan_u4 b = __builtin_amdgcn_raw_buffer_load_b128(s0.rs, sp2 * 1024 + 16 * lane, 0, 0);
+                va = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+                vb = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+            }
+            if (__ballot(!ok) == 0ull) break;
+            if (!poll_backoff(pc, spins, lane)) return false;
+        }
+        plan_quantize_span<FAM>(va, sp, c.lds, k, c.even != 0, lane);
+        if (sp2 < spans) plan_quantize_span<FAM>(vb, sp2, c.lds, k, c.even != 0, lane);
+    }
+    return true;
+}
+
+// One GEMV stage, start to finish, for weight type T:
+//   prime (weights in flight) -> [gather x (polls its producers) -> glue -> quantize x -> LDS] -> stream rows, publishing every y
 template <int T>
-static __device__ __forceinline__ bool plan_stage(StageC st, const Ctx & c, Prog & pr) {
+static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c) {
     // an opaque copy of the lane id per stage: everything derived from it is recomputed here (a few VALU ops) instead
-    // of being hoisted out of the stage loop for every type's loaders, quantizers and pollers and kept live (and spilled)
+    // of being hoisted out of the stage loop for BOTH types' loaders, quantizers and pollers and kept live (and spilled)
     int lane = lane_id(); asm volatile("" : "+v"(lane));
-    const int wave = ufl((int) (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     PLAN_STAMP(0);
     const int k = st->k, flags = st->flags;
-    const unsigned rb = (unsigned) st->row_bytes;
-    int r_lo, r_hi; stage_rows(st, r_lo, r_hi);
-    const bool paired = (flags & PLAN_F_PAIRED) != 0;
-    const int n_items = r_hi - r_lo;                            // rows (PAIRED: pairs) of this workgroup
-    const RowGeom g = row_geom<T>(k);
-    // The consumers take the stage's 1-KiB STEPS in STREAM ORDER, step i to wave i % 15: stream row q = i / steps at byte q * rb, step s = i % steps.
-    const int n_srows = paired ? 2 * n_items : n_items;
-    const int NS = g.steps;
-    const unsigned base = pr.base_page;                         // (bytes)
-    const unsigned stage_bytes = (unsigned) n_srows * rb;
-    int q0 = 0, s0 = wave;                                      // this wave's first step
-    while (s0 >= NS && q0 < n_srows) { s0 -= NS; ++q0; }
-    // this wave needs nothing of the stream before its first step of this stage: tell the loader at once (it fills the ring while we poll)
-    if (lane == 0) cb_st(c.cb + CB_HEAD + 4u * (unsigned) wave, q0 < n_srows ? (base + (unsigned) q0 * rb + 1024u * (unsigned) s0) >> 10 : (base + stage_bytes) >> 10);
-    // the row-slot generations and pair flags of THIS stage were zeroed during the previous GEMV stage (or at launch); zero the other set for the next one
-    const unsigned par = (unsigned) (pr.gemv_idx & 1), gen_cb = c.cb + CB_GEN + 128u * par;
+    int r_lo = (int) blockIdx.x * st->rows_per_wg, r_hi = r_lo + st->rows_per_wg;
+    if (r_hi > st->total_rows) r_hi = st->total_rows;
+    StageW sw;
+    int pair_p0 = 0, pair_np = 0;
+    if (flags & PLAN_F_PAIRED) {                              // rows_per_wg = pairs per workgroup, total_rows = m: local rows [0, 2 np)
+        pair_p0 = r_lo; pair_np = max(0, r_hi - r_lo);
+        sw.load_paired(st, pair_p0, pair_np);
+        r_lo = 0; r_hi = 2 * pair_np;
+    } else sw.load(st);
+    const StageGeom g = plan_geom<T>(k, r_hi);
+
+    constexpr int PLAN_D = plan_depth(T);
+    Chunk ring[PLAN_D];
+    PlanCursor ld;
+    ld.gr = r_lo + (sw.paired ? 2 * wave : wave); ld.s = 0; ld.row = nullptr;
+    if (ld.gr < r_hi) ld.row = sw.row_ptr(ld.gr);
+#ifdef MI355Q_STAMPS
+    { unsigned long long probe = (unsigned long long) (uintptr_t) ld.row + (unsigned) k; asm volatile("" :: "s"(probe)); }   // (forces the descriptor's scalar loads to have returned)
+    PLAN_STAMP(5);
+#endif
+    plan_fill<T, PLAN_D>(ring, 0, st->prime, ld, sw, g, lane);                 // weights start flowing before anything else
+    plan_prefetch_desc(c, wave, lane);
+    PLAN_STAMP(1);
 
     if (flags & PLAN_F_NEW_X) {
         constexpr int FAM = (T == MI355Q_TYPE_Q8_0 || T == MI355Q_TYPE_Q4_0 || T == MI355Q_TYPE_IQ4_NL) ? FAM_Q80 : FAM_Q8K;
+        plan_lds_barrier();                                   // all waves are done with the previous LDS image and staging area
+        if (flags & PLAN_F_DIRECT) {                          // one plain vector: gathered and quantized span by span, one barrier
+            const bool okd = plan_gather_direct<FAM>(st, c, k, wave, lane);
+            if (!okd && lane == 0) c.ctl[CTL_OK] = 0;
+            PLAN_STAMP(2);
+            plan_lds_barrier();
+            if (!c.ctl[CTL_OK]) return false;
+        } else {
         const int x_kind = st->x_kind;
         const float * nw = x_kind == MI355Q_X_NORM ? st->norm_w : nullptr;
         float4 w_first = make_float4(1.f, 1.f, 1.f, 1.f);      // the norm weights of this wave's first span: fetched before the producers are polled
         if (nw && wave * 256 + 4 * lane < k) w_first = *(const float4 *) (nw + wave * 256 + 4 * lane);
-        float4 t[PLAN_MAXS];
         double ssq;
-        PLAN_STATE(1);
-        const bool ok = plan_gather(st, c, k, wave, lane, t, ssq);
-        PLAN_STATE(2);
-        if (!ok && lane == 0) cb_st(c.cb + CB_OK, 0u);
+        const bool ok = plan_gather(st, c, k, wave, lane, ssq);
+        if (!ok && lane == 0) c.ctl[CTL_OK] = 0;
         PLAN_STAMP(2);
         if (x_kind == MI355Q_X_NORM) {
             ssq = wave_sum_f64(ssq);
-            if (lane == 0) *(double *) (c.lds + c.ctl_off + CB_PART + 8 * wave) = ssq;
+            if (lane == 0) c.part[wave] = ssq;
         }
-        // every consumer wave is done with the previous image (its rows of the last stage, or the attention scratch) and has gathered
-        if (!cbar(c, pr, lane)) return false;
+        plan_lds_barrier();
+        if (!c.ctl[CTL_OK]) return false;
         PLAN_STAMP(6);
         float scale = 1.0f;
         if (x_kind == MI355Q_X_NORM) {
-            const double * part = (const double *) (c.lds + c.ctl_off + CB_PART);
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < PLAN_NC; ++i) s += part[i];
+            for (int i = 0; i < GEMV_WAVES; i += 4) s += (c.part[i] + c.part[i + 1]) + (c.part[i + 2] + c.part[i + 3]);
             const float mean = (float) (s / (double) k);
             const float root = (float) sqrt((double) __fadd_rn(mean, st->eps));      // both roundings of the CPU (ops_glue.hip k_add_rms_norm_mul)
             scale = (float) (1.0 / (double) root);
@@ -595,171 +514,65 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const Ctx & c, Prog
         const int spans = (k + 255) >> 8;
         float * x_out = st->x_out;
         const bool pub_x = x_out != nullptr && blockIdx.x == (unsigned) c.stage % c.grid;
-#pragma unroll
-        for (int i = 0; i < PLAN_MAXS; ++i) {
-            const int span = wave + i * PLAN_NC;
-            if (span >= spans) break;                           // (uniform)
+#pragma unroll 1
+        for (int span = wave; span < spans; span += GEMV_WAVES) {
             const int e = span * 256 + 4 * lane;
-            float4 v = t[i];
-            if (x_kind == MI355Q_X_NORM && e < k) {
-                v.x = __fmul_rn(v.x, scale); v.y = __fmul_rn(v.y, scale); v.z = __fmul_rn(v.z, scale); v.w = __fmul_rn(v.w, scale);
-                if (nw) { const float4 ww = i == 0 ? w_first : *(const float4 *) (nw + e); v.x = __fmul_rn(v.x, ww.x); v.y = __fmul_rn(v.y, ww.y); v.z = __fmul_rn(v.z, ww.z); v.w = __fmul_rn(v.w, ww.w); }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < k) {
+                v = *(const float4 *) (c.stg + e);
+                if (x_kind == MI355Q_X_NORM) {
+                    v.x = __fmul_rn(v.x, scale); v.y = __fmul_rn(v.y, scale); v.z = __fmul_rn(v.z, scale); v.w = __fmul_rn(v.w, scale);
+                    if (nw) { const float4 ww = span == wave ? w_first : *(const float4 *) (nw + e); v.x = __fmul_rn(v.x, ww.x); v.y = __fmul_rn(v.y, ww.y); v.z = __fmul_rn(v.z, ww.z); v.w = __fmul_rn(v.w, ww.w); }
+                }
+                if (pub_x) *(float4 *) (x_out + e) = v;         // the formed vector itself is a graph value somebody else reads (result_norm / embeddings, a LoRA branch)
             }
-            if (pub_x && e < k) *(float4 *) (x_out + e) = v;     // the formed vector itself is a graph value somebody else reads (result_norm / embeddings, a LoRA branch)
             plan_quantize_span<FAM>(v, span, c.lds, k, c.even != 0, lane);
         }
         PLAN_STAMP(7);
-        PLAN_STATE(4);
-        if (!cbar(c, pr, lane)) return false;
+        plan_lds_barrier();
+        }
     }
-    else if (!cbar(c, pr, lane)) return false;                 // (a stage that continues on the previous image: the barrier orders the slot reset below)
+    plan_fill<T, PLAN_D>(ring, st->prime, PLAN_D, ld, sw, g, lane);                // top the ring up (a no-op when prime == depth)
+    sw.load_out(st);
     PLAN_STAMP(3);
-    if (wave == 0 && lane < 32) cb_st(c.cb + CB_GEN + 128u * (par ^ 1u) + 4u * (unsigned) lane, 0u);
     ActView av[1];
     av[0].base = c.lds; av[0].k = k;
-    // ROW SLOTS.  A row's steps are computed by different waves; each leaves its lanes' terms (the value gemv_fast.hip adds to the lane's accumulator at
-    // that step) in terms[slot][step][lane], and the wave that took the row's LAST step adds them up in step order -- the very additions of the one-wave
-    // loop, so the sum is bit-identical -- reduces over the lanes and publishes.  Slot = q % R; a slot is reused when its generation says the row R
-    // before has been summed.  Stream order keeps the ring a true FIFO: the pages in use are the ~30 the waves work on, whatever the row length.
-    const int R = min(32, max(2, PLAN_TERM_STEPS / NS));
-    float * terms = (float *) (c.lds + c.ctl_off + CB_BYTES);
-    RowView rv; rv.ring = c.lds + c.ring_off; rv.ring_bytes = c.ring_bytes; rv.off = 0;
-    unsigned landed_seen = 0, spins = 0;
-    PLAN_PROF_DECL;
-    // this wave's current step (all wave-uniform: the readfirstlanes in step() say so and keep the state in SGPRs)
-    int cq = q0, cs = s0, cslot = q0 % R, clap = q0 / R;
-    unsigned coff = (unsigned) q0 * rb;
-    bool more = q0 < n_srows;
-    // request the chunk of step (q, s) once its row has landed (the small fields of its blocks are the row's last bytes) and its slot is free.
-    // wait = false: one look at each condition, no waiting (0 = not yet); returns -1 when a wait gave up
-    auto request = [&](int q, int s, int slot, int lap, unsigned off, Chunk & ch, bool wait) -> int {
-        const unsigned need = (base + off + rb + 1023u) >> 10;
-        while ((int) (landed_seen - need) < 0) {
-            landed_seen = cb_ld(c.cb + CB_LANDED);
-            if ((int) (landed_seen - need) >= 0) break;
-            if (!wait) return 0;
-            if (!lds_spin(c, spins, lane, WHY_LANDED, need, (unsigned) q * 64u + (unsigned) s)) return -1;
-        }
-        if (lap > 0) while ((int) (cb_ld(gen_cb + 4u * (unsigned) slot) - (unsigned) lap) < 0) {
-            if (!wait) return 0;
-            if (!lds_spin(c, spins, lane, WHY_SLOT, (unsigned) q * 64u + (unsigned) s, (unsigned) slot * 65536u + (unsigned) lap)) return -1;
-        }
-        spins = 0;
-        rv.off = uflu(ring_pos(c, base + off));
-        if (64 * s + lane < g.nchunks) {
-            if (rv.off + rb <= c.ring_bytes) chunk_lds<T, false>(ch, rv, g.nb, s, lane);      // (uniform branch)
-            else                            chunk_lds<T, true>(ch, rv, g.nb, s, lane);
-        }
-        return 1;
-    };
-    // one step: request this wave's NEXT chunk into `other` if that needs no waiting, then the arithmetic of the current one (`mine`) and its terms;
-    // the wave whose arrival completes a row closes it (nobody waits for anybody: the counter wraps to 0 with the last arrival)
-    auto step = [&](Chunk & mine, Chunk & other) -> bool {
-        cq = ufl(cq); cs = ufl(cs); cslot = ufl(cslot); clap = ufl(clap); coff = uflu(coff); landed_seen = uflu(landed_seen);
-        int nq = cq, ns = cs + PLAN_NC, nslot = cslot, nlap = clap; unsigned noff = coff;
-        while (ns >= NS) { ns -= NS; ++nq; noff += rb; if (++nslot == R) { nslot = 0; ++nlap; } }
-        const bool nmore = nq < n_srows;
-        // (the LDS unit executes a wave's instructions in order: this word is written after the reads of every earlier step have been performed)
-        if (lane == 0) cb_st(c.cb + CB_HEAD + 4u * (unsigned) wave, (base + coff + 1024u * (unsigned) cs) >> 10);
-        PLAN_PROF(0);
-        PLAN_STATE(0x50000 | (nq & 0xFFFF));
-        int have = 0;
-        if (nmore) { have = ufl(request(nq, ns, nslot, nlap, noff, other, false)); if (have < 0) return false; }
-        PLAN_STATE(0x60000 | (cq & 0xFFFF));
-        PLAN_PROF(1);
-        float acc[1] = { 0.0f };
-        if (64 * cs + lane < g.nchunks) Consume<T, 1>::run(mine, cs, lane, av, acc);
-        terms[(cslot * NS + cs) * 64 + lane] = acc[0];
-        asm volatile("" ::: "memory");                          // (program order: the term store is issued before the arrival; the LDS unit keeps that order)
-        const unsigned arrived = cb_arrive(c.cb + CB_CNT + 4u * (unsigned) cslot, (unsigned) NS - 1u, lane);
-        PLAN_PROF(2);
-        if (arrived == (unsigned) NS - 1u) {                     // the row is complete: its terms, added in step order
-            PLAN_STATE(0x70000 | (cq & 0xFFFF));
-            float a = 0.0f;
-#pragma unroll 1
-            for (int ss = 0; ss < NS; ++ss) a += terms[(cslot * NS + ss) * 64 + lane];
-            const float d = wave_sum(a);
-            asm volatile("" ::: "memory");
-            if (lane == 0) cb_st(gen_cb + 4u * (unsigned) cslot, (unsigned) clap + 1u);      // (after the reads above: the slot may take its next row)
-            const unsigned tag = c.epoch + st->tag_off;
-            const bool plain = (st->flags & PLAN_F_PLAIN_Y) != 0;
-            if (!paired) {
-                if (lane == 0) {
-                    const int gr = r_lo + cq;
-                    publish(st->yg + gr, d, tag);
-                    if (plain) {
-                        const int b1 = st->row_begin[1], b2 = st->row_begin[2], b3 = st->row_begin[3];
-                        const int mi = (gr >= b1) + (gr >= b2) + (gr >= b3);
-                        float * y = mi == 0 ? st->y[0] : mi == 1 ? st->y[1] : mi == 2 ? st->y[2] : st->y[3];
-                        y[gr - (mi == 0 ? 0 : mi == 1 ? b1 : mi == 2 ? b2 : b3)] = d;
-                    }
-                }
-            } else {
-                const int glog = st->glog, G = 1 << glog;
-                const int g0 = (cq >> (glog + 1)) << glog, w = cq & (2 * G - 1), n_g = min(G, n_items - g0);
-                const int which = w >= n_g ? 1 : 0, p = g0 + w - which * n_g;
-                // the pair's two dot products meet in LDS: each closer leaves its value, the second to arrive forms the product
-                if (lane == 0) cb_st(c.cb + CB_PDV + 256u * (unsigned) which + 4u * (unsigned) (p & 63), __float_as_uint(d));
-                if (cb_arrive(c.cb + CB_PCNT + 4u * (unsigned) (p & 63), 1u, lane) == 1u) {
-                    const float dg = which ? __uint_as_float(cb_ld(c.cb + CB_PDV + 4u * (unsigned) (p & 63))) : d;
-                    const float du = which ? d : __uint_as_float(cb_ld(c.cb + CB_PDV + 256u + 4u * (unsigned) (p & 63)));
-                    if (lane == 0) {
-                        const float r = __fmul_rn(unary_f(st->x_unary >> 8, dg), du);      // (a PAIRED stage keeps its output unary in the high byte of x_unary)
-                        publish(st->yg + r_lo + p, r, tag);
-                        if (plain) st->y[0][r_lo + p] = r;
-                    }
-                }
-            }
-            PLAN_PROF(3);
-        }
-        if (nmore && !have) { if (ufl(request(nq, ns, nslot, nlap, noff, other, true)) < 0) return false; PLAN_PROF(4); }
-        cq = nq; cs = ns; cslot = nslot; clap = nlap; coff = noff; more = nmore;
-        return true;
-    };
-    Chunk chA, chB;
-    bool ok_rows = true;
-    if (more) { ok_rows = ufl(request(cq, cs, cslot, clap, coff, chA, true)) > 0; PLAN_STAMP(1); }
-#pragma unroll 1
-    while (more && ok_rows) {
-        ok_rows = step(chA, chB);
-        if (!more || !ok_rows) break;
-        ok_rows = step(chB, chA);
-    }
-    if (!ok_rows) { if (lane == 0) cb_st(c.cb + CB_OK, 0u); return false; }
-    if (lane == 0) cb_st(c.cb + CB_HEAD + 4u * (unsigned) wave, (base + stage_bytes) >> 10);
-    PLAN_PROF_FLUSH;
-    PLAN_STATE(9);
-    ++pr.gemv_idx;
-    pr.base_page = base + stage_bytes;
+    // (a PAIRED stage publishes unary(row of matrix 0) * (row of matrix 1) per pair from the wave that streamed both: the output unary is kept in
+    // the high byte of x_unary)
+    plan_run<T, PLAN_D>(ring, ld, sw, g, r_lo, wave, lane, av, c.epoch + st->tag_off, (flags & PLAN_F_PLAIN_Y) != 0, pair_p0, st->x_unary >> 8);
     PLAN_STAMP(4);
     return true;
 }
 
 // ---- attention of one token ------------------------------------------------------------------------------------------
-// Workgroup b = (head h, KV split sp), consumer waves only.  LDS (the image area: no image is live during an ATTN stage): sq / sk / sv f32 [hd],
-// kh / vh f16 [hd] (this token's cache row, rounded as stored), sc f32 [per] (scores, then probabilities), red f32 [15][hd] (P V partials), maxs / sums.
+// Workgroup b = (head h, KV split sp).  LDS (inside the staging area): sq / sk / sv f32 [hd], kh / vh f16 [hd] (this token's
+// cache row, rounded as stored), sc f32 [per] (scores, then probabilities), red f32 [16][hd] (P V partials), maxs / sums [16].
 typedef const __attribute__((address_space(4))) AttnStage * AttnC;          // the descriptor is read with scalar loads
 
-static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsigned tag_in, unsigned * bar_io) {
+static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in, unsigned tag_in) {
     const AttnC a = (AttnC) (uintptr_t) uniform_ptr((const void *) (uintptr_t) a_in);      // (see uniform_ptr)
     // LDS pointers are re-derived from the kernel's LDS symbol: taken from the caller's struct they would be generic pointers (flat loads)
     extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds_attn[];
-    Ctx c = c_in;
-    c.lds = plan_lds_attn; c.cb = uflu(c_in.cb); c.sync = uniform_ptr(c_in.sync);
-    c.grid = uflu(c_in.grid); c.epoch = uflu(c_in.epoch); c.stage = ufl(c_in.stage);
-    Prog pr; pr.gemv_idx = 0; pr.base_page = 0; pr.bar_target = uflu(*bar_io);
-    const unsigned tag = uflu(tag_in);
+    StageCtx c;
+    c.image = __builtin_amdgcn_readfirstlane(c_in.image);
+    c.lds = plan_lds_attn; c.ctl = (int *) (plan_lds_attn + c.image); c.part = (double *) (plan_lds_attn + c.image + 64);
+    c.stg = (float *) (plan_lds_attn + c.image + 64 + 8 * GEMV_WAVES + 1024);
+    c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
+    c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
+    c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
+    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.pre_lds = c_in.pre_lds;
+    const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
     const int lane = lane_id();
-    const int wave = ufl((int) (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int tid = (int) threadIdx.x;
     const int hd = a->hd, n_split = a->n_split;
     if ((int) blockIdx.x >= a->n_head * n_split) return true;                    // (uniform: the whole workgroup has nothing to do)
     const int h = (int) blockIdx.x / n_split, sp = (int) blockIdx.x % n_split, gq = a->n_head / a->n_head_kv, g = h / gq;
-    float * sq = (float *) c.lds, * sk = sq + hd, * sv = sk + hd;
+    float * sq = c.stg, * sk = sq + hd, * sv = sk + hd;
     __half * kh = (__half *) (sv + hd), * vh = kh + hd;
     float * maxs = (float *) (vh + hd), * sums = maxs + GEMV_WAVES;
-    float * red = sums + GEMV_WAVES;                                          // [15][hd]
-    float * sc = red + PLAN_NC * hd;                                           // [per]
+    float * red = sums + GEMV_WAVES;                                          // [16][hd]
+    float * sc = red + GEMV_WAVES * hd;                                        // [per]
     // loads that depend on nothing this launch computes are issued first: the token's position, its cache slots, the window, the mask
     const int32_t * pos_p = a->pos, * nkv_p = a->n_kv_dev;
     char * const * kdst_p = a->k_dst, * const * vdst_p = a->v_dst;
@@ -770,18 +583,19 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
     const int per = (n_kv + n_split - 1) / n_split;
     const int j0 = sp * per, j1 = min(n_kv, j0 + per), cnt = max(0, j1 - j0);
     const char * maskp = a->mask; const int mask_f16 = a->mask_f16;
-    bool ok_bar = cbar(c, pr, lane);                                               // the image area is free (the previous stage's rows are done)
+    plan_lds_barrier();                                                        // the staging area is free (previous stage's quantizer is done)
+    plan_prefetch_desc(c, wave, lane);
     PLAN_STAMP(0);
-    if (ok_bar) for (int jj = tid; jj < cnt; jj += PLAN_CT)                    // the additive mask of this split's positions (0 without a mask)
+    for (int jj = tid; jj < cnt; jj += GEMV_THREADS)                           // the additive mask of this split's positions (0 without a mask)
         sc[jj] = maskp ? (mask_f16 ? __half2float(((const __half *) maskp)[j0 + jj]) : ((const float *) maskp)[j0 + jj]) : 0.0f;
 
     // 1. q head h, k / v head g  (hd <= 256: at most two 128-element chunks each)
-    if (ok_bar) {
-        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime(); pc.stage = c.stage;
+    {
+        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         const int nch = (hd + 127) >> 7;
         bool ok_all = true;
-        for (int item = wave; item < 3 * nch; item += PLAN_NC) {
+        for (int item = wave; item < 3 * nch; item += GEMV_WAVES) {
             const int which = item / nch, ch = item % nch;
             VecSrc vs;
             if (which == 0)      { vs.plain = a->q.plain; vs.gran = a->q.gran; vs.tag_off = a->q.tag_off; }
@@ -800,9 +614,10 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
             const int e = 128 * ch + 2 * lane;
             if (e < hd) { dst[e] = v0; dst[e + 1] = v1; }
         }
-        if (!ok_all && lane == 0) cb_st(c.cb + CB_OK, 0u);
+        if (!ok_all && lane == 0) c.ctl[CTL_OK] = 0;
     }
-    if (!ok_bar || !cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+    plan_lds_barrier();
+    if (!c.ctl[CTL_OK]) return false;
     PLAN_STAMP(1);
 
     // 2. rope (ops_glue.hip k_rope / ggml-cpu/ops.cpp:5088-5270); q is then rounded to f16 as the CPU's f16 vec_dot does with src1,
@@ -841,7 +656,7 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
         const int d = tid - 2 * half;
         vh[d] = __float2half_rn(sv[d]);
     }
-    if (!cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+    plan_lds_barrier();
     if (sp == 0 && h % gq == 0 && tid < hd) {                                   // this token's cache row: one workgroup per kv head stores it
         ((__half *) kdst)[g * hd + tid] = kh[tid];
         *(__half *) (vdst + (int64_t) (g * hd + tid) * a->v_dst_nb) = vh[tid];
@@ -858,13 +673,13 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
     const float q2 = 2 * lane + 128 < hd ? sq[2 * lane + 128] : 0.f, q3 = 2 * lane + 128 < hd ? sq[2 * lane + 129] : 0.f;
     constexpr int SB = 8;
 #pragma unroll 1
-    for (int jb = wave; jb < cnt; jb += SB * PLAN_NC) {
+    for (int jb = wave; jb < cnt; jb += SB * GEMV_WAVES) {
         __half2 kv[SB], kw[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int j = j0 + jb + u * PLAN_NC;
+            const int j = j0 + jb + u * GEMV_WAVES;
             kv[u] = __half2(); kw[u] = __half2();
-            if (jb + u * PLAN_NC < cnt) {
+            if (jb + u * GEMV_WAVES < cnt) {
                 if (j == slot) { if (2 * lane < hd) kv[u] = *(const __half2 *) (kh + 2 * lane); if (2 * lane + 128 < hd) kw[u] = *(const __half2 *) (kh + 2 * lane + 128); }
                 else {
                     const char * row = kbase + (int64_t) j * k_nb_pos;
@@ -875,19 +690,19 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            if (jb + u * PLAN_NC < cnt) {
+            if (jb + u * GEMV_WAVES < cnt) {
                 const float2 f = __half22float2(kv[u]), f2 = __half22float2(kw[u]);
                 float d = q0 * f.x + q1 * f.y + q2 * f2.x + q3 * f2.y;
                 d = wave_sum(d);
                 // (a fully masked position stays -inf whatever its cache row holds: never-written rows may be anything, 0 * NaN included)
-                if (lane == 0) { const float m = sc[jb + u * PLAN_NC]; sc[jb + u * PLAN_NC] = m == -INFINITY ? -INFINITY : __fadd_rn(__fmul_rn(d, scale), m); }
+                if (lane == 0) { const float m = sc[jb + u * GEMV_WAVES]; sc[jb + u * GEMV_WAVES] = m == -INFINITY ? -INFINITY : __fadd_rn(__fmul_rn(d, scale), m); }
             }
         }
     }
-    if (!cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+    plan_lds_barrier();
     PLAN_STAMP(3);
     // 4. local softmax statistics.  A split holds at most a few hundred scores: ONE wave forms maximum, exponentials, sum and (single split) the
-    //    probabilities with register reductions, the other 14 wait at one barrier -- the workgroup-wide form cost three barriers for the same numbers.
+    //    probabilities with register reductions, the other 15 wait at one barrier -- the workgroup-wide form cost three barriers for the same numbers.
     if (wave == 0) {
         float mx0 = -INFINITY;
         for (int j = lane; j < cnt; j += 64) mx0 = fmaxf(mx0, sc[j]);
@@ -917,21 +732,21 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
         }
         if (lane == 0) { maxs[0] = mx0; sums[0] = l0; }
     }
-    if (!cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+    plan_lds_barrier();
     const float mx = maxs[0], l = sums[0];
     PLAN_STAMP(4);
     // 5. o[d] = sum_j p_j v[j][d]   (positions with p == 0 are skipped: masked cache rows may hold anything)
     const char * vbase = a->v_cache + (int64_t) g * a->v_nb_head;
     const int64_t v_nb_pos = a->v_nb_pos, v_nb_dim = a->v_nb_dim;
     if (v_nb_dim == 2) {
-        // rows per position (the -fa layout): a wave takes positions jb = wave, wave+15, ...; a lane owns dims (2l, 2l+1) [+128]
+        // rows per position (the -fa layout): a wave takes positions jb = wave, wave+16, ...; a lane owns dims (2l, 2l+1) [+128]
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 1
-        for (int jb = wave; jb < cnt; jb += SB * PLAN_NC) {
+        for (int jb = wave; jb < cnt; jb += SB * GEMV_WAVES) {
             __half2 vv[SB], vw[SB]; float p[SB];
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
-                const int jj = jb + u * PLAN_NC, j = j0 + jj;
+                const int jj = jb + u * GEMV_WAVES, j = j0 + jj;
                 vv[u] = __half2(); vw[u] = __half2(); p[u] = jj < cnt ? sc[jj] : 0.0f;
                 if (p[u] != 0.0f) {
                     if (j == slot) { if (2 * lane < hd) vv[u] = *(const __half2 *) (vh + 2 * lane); if (2 * lane + 128 < hd) vw[u] = *(const __half2 *) (vh + 2 * lane + 128); }
@@ -950,18 +765,18 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
         }
         if (2 * lane < hd) { red[wave * hd + 2 * lane] = o0; red[wave * hd + 2 * lane + 1] = o1; }
         if (2 * lane + 128 < hd) { red[wave * hd + 2 * lane + 128] = o2; red[wave * hd + 2 * lane + 129] = o3; }
-        if (!cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+        plan_lds_barrier();
         if (tid < hd) {
             float o = 0.0f;
 #pragma unroll
-            for (int i = 0; i < PLAN_NC; ++i) o += red[i * hd + tid];
+            for (int i = 0; i < GEMV_WAVES; ++i) o += red[i * hd + tid];
             red[tid] = o;                                                      // (row 0 of red now holds o; every thread touches only its column)
         }
     } else {
-        // transposed cache (positions contiguous per dim): a wave takes dims d = wave + 15 i; lanes run over the positions; the loads of
+        // transposed cache (positions contiguous per dim): a wave takes dims d = wave + 16 i; lanes run over the positions; the loads of
         // 8 dims are in flight together (one memory round trip per 64 positions instead of one per dim)
 #pragma unroll 1
-        for (int d0 = wave; d0 < hd; d0 += SB * PLAN_NC) {
+        for (int d0 = wave; d0 < hd; d0 += SB * GEMV_WAVES) {
             float o[SB];
 #pragma unroll
             for (int u = 0; u < SB; ++u) o[u] = 0.0f;
@@ -972,7 +787,7 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
                 __half vv[SB];
 #pragma unroll
                 for (int u = 0; u < SB; ++u) {
-                    const int d = d0 + u * PLAN_NC;
+                    const int d = d0 + u * GEMV_WAVES;
                     vv[u] = __half();
                     if (p != 0.0f && d < hd) vv[u] = j == slot ? vh[d] : *(const __half *) (vbase + (int64_t) d * v_nb_dim + (int64_t) j * v_nb_pos);
                 }
@@ -981,12 +796,12 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
             }
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
-                const int d = d0 + u * PLAN_NC;
+                const int d = d0 + u * GEMV_WAVES;
                 if (d < hd) { const float t = wave_sum(o[u]); if (lane == 0) red[d] = t; }     // (d wave-uniform)
             }
         }
     }
-    if (!cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+    plan_lds_barrier();
     // 6. publish: the normalized output when the head is not split, else (o, m, l) of this split for the merge stage
     if (n_split == 1) {
         if (tid < hd) {
@@ -1001,36 +816,39 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const Ctx & c_in, unsi
         else if (tid == hd + 1) publish(part + hd + 1, l, tag);
     }
     PLAN_STAMP(5);
-    *bar_io = pr.bar_target;
     return true;
 }
 
 // merge the KV splits of a head: out = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s     (workgroup h * n_split does head h)
-static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const Ctx & c_in, unsigned tag_in, unsigned * bar_io) {
+static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const StageCtx & c_in, unsigned tag_in) {
     const AttnC a = (AttnC) (uintptr_t) uniform_ptr((const void *) (uintptr_t) a_in);
-    const unsigned tag = uflu(tag_in);
+    const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
     extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds_comb[];
-    Ctx c = c_in;
-    c.lds = plan_lds_comb; c.cb = uflu(c_in.cb); c.sync = uniform_ptr(c_in.sync);
-    c.grid = uflu(c_in.grid); c.epoch = uflu(c_in.epoch); c.stage = ufl(c_in.stage);
-    Prog pr; pr.gemv_idx = 0; pr.base_page = 0; pr.bar_target = uflu(*bar_io);
+    StageCtx c;
+    c.image = __builtin_amdgcn_readfirstlane(c_in.image);
+    c.lds = plan_lds_comb; c.ctl = (int *) (plan_lds_comb + c.image); c.part = (double *) (plan_lds_comb + c.image + 64);
+    c.stg = (float *) (plan_lds_comb + c.image + 64 + 8 * GEMV_WAVES + 1024);
+    c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
+    c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
+    c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
+    c.next_desc = nullptr; c.next_attn = nullptr; c.pre_lds = c_in.pre_lds;
     const int lane = lane_id();
-    const int wave = ufl((int) (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int tid = (int) threadIdx.x;
     const int hd = a->hd, n_split = a->n_split;
     if ((int) blockIdx.x >= a->n_head * n_split || (int) blockIdx.x % n_split != 0) return true;
     const int h = (int) blockIdx.x / n_split;
     const int n = n_split * (hd + 2);
-    float * buf = (float *) c.lds;
-    bool ok_bar = cbar(c, pr, lane);
+    float * buf = c.stg;
+    plan_lds_barrier();
     PLAN_STAMP(0);
-    if (ok_bar) {
+    {
         VecSrc vs; vs.plain = nullptr; vs.gran = a->part + (size_t) h * n; vs.tag_off = 0; vs.pad = 0;
         SrcView s = src_view(vs, 0, n, 0); s.expect = tag - 1;                  // the partials carry the ATTN stage's tag (the stage before this one)
-        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime(); pc.stage = c.stage;
+        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         bool ok_all = true;
-        for (int ch = wave; ch < ((n + 127) >> 7); ch += PLAN_NC) {
+        for (int ch = wave; ch < ((n + 127) >> 7); ch += GEMV_WAVES) {
             float v0, v1;
             for (;;) {
                 const bool ok = src_try(s, ch, lane, v0, v1) || 128 * ch + 2 * lane >= n;
@@ -1041,9 +859,10 @@ static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const Ctx & c_
             const int e = 128 * ch + 2 * lane;
             if (e < n) { buf[e] = v0; buf[e + 1] = v1; }
         }
-        if (!ok_all && lane == 0) cb_st(c.cb + CB_OK, 0u);
+        if (!ok_all && lane == 0) c.ctl[CTL_OK] = 0;
     }
-    if (!ok_bar || !cbar(c, pr, lane)) { *bar_io = pr.bar_target; return false; }
+    plan_lds_barrier();
+    if (!c.ctl[CTL_OK]) return false;
     if (tid < hd) {
         float M = -INFINITY;
         for (int s = 0; s < n_split; ++s) M = fmaxf(M, buf[s * (hd + 2) + hd]);
@@ -1059,56 +878,47 @@ static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const Ctx & c_
         if (a->plain) a->out_plain[h * hd + tid] = r;
     }
     PLAN_STAMP(2);
-    *bar_io = pr.bar_target;
     return true;
 }
 
 template <unsigned SET>
 __global__ void __launch_bounds__(GEMV_THREADS)
-k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsigned long long timeout_ticks, int ctl_off, int ring_off, int np, unsigned ring_magic, unsigned epoch) {
+k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsigned long long timeout_ticks, int lds_image_bytes, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     StageC stages = (StageC) stages_g;
     if (__hip_atomic_load(sync + PLAN_SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // sticky: a plan that timed out stays dead
 
-    Ctx c;
-    c.lds = lds; c.cb = (unsigned) (size_t) lds + (unsigned) ctl_off;
-    c.ring_off = (unsigned) ring_off; c.np = (unsigned) np; c.ring_bytes = (unsigned) np * 1024u; c.ring_magic = ring_magic; c.np_magic = (unsigned) (0x100000000ull / (unsigned long long) np);
-    c.sync = sync; c.timeout = timeout_ticks; c.grid = gridDim.x; c.even = even; c.epoch = epoch;
-    c.stage = 0; c.ctl_off = (unsigned) ctl_off;
-    Prog pr; pr.gemv_idx = 0; pr.base_page = 0; pr.bar_target = 0;
-    if (threadIdx.x < CB_BYTES / 4) {
-        unsigned v = 0;
-        if (threadIdx.x == CB_OK / 4) v = 1u;
-        if (threadIdx.x == CB_HEAD / 4 + PLAN_NC) v = 0xFFFFFFFFu;          // the word behind the consumers' heads: the loader's minimum ignores it
-        ((unsigned *) (lds + ctl_off))[threadIdx.x] = v;
-    }
-    __syncthreads();                                                          // the ONLY hardware barrier of the launch: the loader never joins another one
-    const int wave = ufl((int) (threadIdx.x >> 6));
-    if (wave == PLAN_NC) { plan_loader(stages, n_stages, c); return; }
+    StageCtx c;
+    c.lds = lds; c.ctl = (int *) (lds + lds_image_bytes); c.part = (double *) (lds + lds_image_bytes + 64);
+    c.stg = (float *) (lds + lds_image_bytes + 64 + 8 * GEMV_WAVES + 1024);
+    c.pre_lds = (unsigned) (size_t) (lds + lds_image_bytes + 64 + 8 * GEMV_WAVES);
+    c.sync = sync; c.timeout = timeout_ticks; c.grid = gridDim.x; c.even = even; c.epoch = epoch; c.image = lds_image_bytes;
+    if (threadIdx.x == 0) c.ctl[CTL_OK] = 1;
+    plan_lds_barrier();
 
 #pragma unroll 1
     for (int s = 0; s < n_stages; ++s) {
         StageC st = stages + s;
         c.stage = s;
+        c.next_desc = s + 1 < n_stages ? (const uint8_t *) (stages_g + s + 1) : nullptr;
+        c.next_attn = (const uint8_t *) st->next_attn;
         bool ok = true;
         const int kind = st->kind;
         if (kind == PLAN_K_GEMV) {
-            bool ran = false;
             switch (st->type) {
-            case MI355Q_TYPE_Q4_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_K)) != 0) { ok = plan_stage<MI355Q_TYPE_Q4_K>(st, c, pr); ran = true; } break;
-            case MI355Q_TYPE_Q5_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q5_K)) != 0) { ok = plan_stage<MI355Q_TYPE_Q5_K>(st, c, pr); ran = true; } break;
-            case MI355Q_TYPE_Q6_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q6_K)) != 0) { ok = plan_stage<MI355Q_TYPE_Q6_K>(st, c, pr); ran = true; } break;
-            case MI355Q_TYPE_Q8_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q8_0)) != 0) { ok = plan_stage<MI355Q_TYPE_Q8_0>(st, c, pr); ran = true; } break;
-            case MI355Q_TYPE_Q4_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_0)) != 0) { ok = plan_stage<MI355Q_TYPE_Q4_0>(st, c, pr); ran = true; } break;
-            case MI355Q_TYPE_IQ4_NL: if constexpr ((SET & tbit(MI355Q_TYPE_IQ4_NL)) != 0) { ok = plan_stage<MI355Q_TYPE_IQ4_NL>(st, c, pr); ran = true; } break;
-            case MI355Q_TYPE_IQ4_XS: if constexpr ((SET & tbit(MI355Q_TYPE_IQ4_XS)) != 0) { ok = plan_stage<MI355Q_TYPE_IQ4_XS>(st, c, pr); ran = true; } break;
+            case MI355Q_TYPE_Q4_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_K>(st, c); break;
+            case MI355Q_TYPE_Q5_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q5_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q5_K>(st, c); break;
+            case MI355Q_TYPE_Q6_K: if constexpr ((SET & tbit(MI355Q_TYPE_Q6_K)) != 0) ok = plan_stage<MI355Q_TYPE_Q6_K>(st, c); break;
+            case MI355Q_TYPE_Q8_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q8_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q8_0>(st, c); break;
+            case MI355Q_TYPE_Q4_0: if constexpr ((SET & tbit(MI355Q_TYPE_Q4_0)) != 0) ok = plan_stage<MI355Q_TYPE_Q4_0>(st, c); break;
+            case MI355Q_TYPE_IQ4_NL: if constexpr ((SET & tbit(MI355Q_TYPE_IQ4_NL)) != 0) ok = plan_stage<MI355Q_TYPE_IQ4_NL>(st, c); break;
+            case MI355Q_TYPE_IQ4_XS: if constexpr ((SET & tbit(MI355Q_TYPE_IQ4_XS)) != 0) ok = plan_stage<MI355Q_TYPE_IQ4_XS>(st, c); break;
             default: break;
             }
-            if (!ran) { pr.base_page += stage_stream_bytes(st); ++pr.gemv_idx; }      // (a type outside this instantiation's set: never happens for a created plan)
         } else if (kind == PLAN_K_ATTN) {
-            { unsigned bar = pr.bar_target; ok = plan_attn((AttnC) st->attn, c, epoch + st->tag_off, &bar); pr.bar_target = bar; }
+            ok = plan_attn((AttnC) st->attn, c, epoch + st->tag_off);
         } else {
-            { unsigned bar = pr.bar_target; ok = plan_attn_combine((AttnC) st->attn, c, epoch + st->tag_off, &bar); pr.bar_target = bar; }
+            ok = plan_attn_combine((AttnC) st->attn, c, epoch + st->tag_off);
         }
         if (!ok) return;
     }
@@ -1120,8 +930,7 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
 struct Plan {
     int           device = 0, n_cu = 0, grid = 0, n_stages = 0, even = 0;
     unsigned      set = 0;
-    size_t        lds_total = 0;
-    int           ctl_off = 0, ring_off = 0, np = 0;
+    size_t        lds_image = 0, lds_total = 0;
     int64_t       weight_bytes = 0;
     PlanStage *   d_stages = nullptr;
     AttnStage *   d_attn = nullptr;
@@ -1160,7 +969,7 @@ void mi355q_set_error(const char * msg);          // api.hip
 // outputs published so far while the stage list is built: [ptr, ptr + n) f32 <-> granule offset, producing stage
 namespace { struct OutRange { const float * p; int64_t n; size_t gran_off; unsigned tag_off; int64_t id; }; }
 
-int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_stages, int flags) {
+int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_stages, int flags) {
     if (!out || !stages || n_stages < 1) { mi355q_set_error("plan_create: null argument / no stages"); return MI355Q_ERR_SHAPE; }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { mi355q_set_error("plan_create: no device"); return MI355Q_ERR_HIP; }
@@ -1173,7 +982,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
     size_t gran_count = 0;
     auto new_out = [&](const float * p, int64_t n, unsigned tag_off, int64_t id) {
         OutRange r = { p, n, gran_count, tag_off, id };
-        gran_count += (size_t) ((n + 3) & ~(int64_t) 3);       // keep every vector 32-byte aligned (a lane's four granules are two 16-byte loads)
+        gran_count += (size_t) ((n + 1) & ~(int64_t) 1);       // keep every vector 16-byte aligned
         outs.push_back(r);
         return r.gran_off;
     };
@@ -1196,8 +1005,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
         }
         return !overlapped;                                    // a plain operand whose memory a stage of this plan overwrites: not expressible
     };
-    auto overlaps = [](const float * a, int64_t na, const float * b, int64_t nb) { return a && b && a < b + nb && b < a + na; };
-    unsigned set = 0; size_t img_max = 0; int64_t bytes = 0; size_t row_max = 0;
+    unsigned set = 0; size_t lds_max = 0, stg_max = 0; int64_t bytes = 0;
     for (int s = 0; s < n_stages; ++s) {
         const mi355q_stage & in = stages[s];
         if (in.kind == MI355Q_STAGE_ATTN) {
@@ -1230,43 +1038,41 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 A.corr0 = start > 0 ? start : 0; A.corr1 = end < at->rope.n_dims - 1 ? end : (float) (at->rope.n_dims - 1);
             }
             // internal stages: attention per (head, split) and, when the heads are split, the merge
-            PlanStage p = {}; p.kind = PLAN_K_ATTN; p.kf = PLAN_K_ATTN; p.tag_off = (unsigned) v.size() + 1; p.flags = PLAN_F_NEW_X;
+            PlanStage p = {}; p.kind = PLAN_K_ATTN; p.tag_off = (unsigned) v.size() + 1; p.flags = PLAN_F_NEW_X;
             if (A.n_split == 1) {
                 A.out_gran = (Granule *) (uintptr_t) (new_out(at->out, (int64_t) at->n_head * hd, p.tag_off, at->out_id) + 1);
                 v.push_back(p); attn_of.push_back((int) va.size());
             } else {
-                const size_t part_off = gran_count; gran_count += (size_t) at->n_head * A.n_split * (hd + 2); gran_count = (gran_count + 3) & ~(size_t) 3;
+                const size_t part_off = gran_count; gran_count += (size_t) at->n_head * A.n_split * (hd + 2); gran_count = (gran_count + 1) & ~(size_t) 1;
                 A.part = (Granule *) (uintptr_t) (part_off + 1);
                 v.push_back(p); attn_of.push_back((int) va.size());
-                PlanStage q = {}; q.kind = PLAN_K_COMBINE; q.kf = PLAN_K_COMBINE; q.tag_off = (unsigned) v.size() + 1; q.flags = PLAN_F_NEW_X;
+                PlanStage q = {}; q.kind = PLAN_K_COMBINE; q.tag_off = (unsigned) v.size() + 1; q.flags = PLAN_F_NEW_X;
                 A.out_gran = (Granule *) (uintptr_t) (new_out(at->out, (int64_t) at->n_head * hd, q.tag_off, at->out_id) + 1);
                 v.push_back(q); attn_of.push_back((int) va.size());
             }
             va.push_back(A);
-            const size_t need = (size_t) 4 * (3 * hd + hd /* kh, vh */ + 2 * GEMV_WAVES + PLAN_NC * hd + A.per) + 64;
+            const size_t need = (size_t) 4 * (3 * hd + hd /* kh, vh */ + 2 * GEMV_WAVES + GEMV_WAVES * hd + A.per) + 64;
             const size_t need2 = (size_t) 4 * A.n_split * (hd + 2) + 64;
-            if (need > img_max) img_max = need;
-            if (need2 > img_max) img_max = need2;
+            if (need > stg_max) stg_max = need;
+            if (need2 > stg_max) stg_max = need2;
             bytes += (int64_t) 2 * at->n_kv * at->n_head_kv * hd * 2;
             continue;
         }
         if (in.kind != MI355Q_STAGE_GEMV) { mi355q_set_error("plan_create: unknown stage kind"); return MI355Q_ERR_UNSUPPORTED; }
-        if (in.n_mats < 1 || in.n_mats > GEMV_MAX_MATS || !in.x || in.k <= 0 || (in.k & 31) || ((uintptr_t) in.x & 15)) { mi355q_set_error("plan_create: bad stage (k % 32, x 16-byte aligned)"); return MI355Q_ERR_SHAPE; }
-        if (in.k > (int64_t) PLAN_MAXS * PLAN_NC * 256) { mi355q_set_error("plan_create: k too large for the gather registers"); return MI355Q_ERR_UNSUPPORTED; }
+        if (in.n_mats < 1 || in.n_mats > GEMV_MAX_MATS || !in.x || in.k <= 0 || (in.k & 31) || ((uintptr_t) in.x & 7)) { mi355q_set_error("plan_create: bad stage"); return MI355Q_ERR_SHAPE; }
         if (in.x_kind < MI355Q_X_PLAIN || in.x_kind > MI355Q_X_UNARY_MUL) { mi355q_set_error("plan_create: unknown x_kind"); return MI355Q_ERR_UNSUPPORTED; }
         if (in.x_kind == MI355Q_X_UNARY_MUL && (!in.x1 || (in.x_unary != MI355Q_UNARY_SILU && in.x_unary != MI355Q_UNARY_RELU && in.x_unary != MI355Q_UNARY_SIGMOID))) { mi355q_set_error("plan_create: X_UNARY_MUL needs x1 and SILU / RELU / SIGMOID"); return MI355Q_ERR_UNSUPPORTED; }
         if (in.x_kind == MI355Q_X_PLAIN && in.x1) { mi355q_set_error("plan_create: X_PLAIN takes one operand"); return MI355Q_ERR_SHAPE; }
         if (in.x_kind == MI355Q_X_NORM && (((uintptr_t) in.norm_w & 15) || (in.k & 3))) { mi355q_set_error("plan_create: norm weights must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
-        if (in.x1 && ((uintptr_t) in.x1 & 15)) { mi355q_set_error("plan_create: x1 must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
-        if ((in.sum_out && ((uintptr_t) in.sum_out & 15)) || (in.x_out && ((uintptr_t) in.x_out & 15))) { mi355q_set_error("plan_create: sum_out / x_out must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
-        // a plain store of this stage must not land on a plain operand the same stage still reads in other workgroups (ggml-alloc makes ADD in place)
-        if (in.sum_out && !(in.flags & MI355Q_STAGE_NO_PLAIN)) {
+        if (in.x1 && ((uintptr_t) in.x1 & 7)) { mi355q_set_error("plan_create: x1 must be 8-byte aligned"); return MI355Q_ERR_ALIGN; }
+        if (in.x_out && (((uintptr_t) in.x_out & 15) || (in.k & 3) || in.x_kind == MI355Q_X_PLAIN)) { mi355q_set_error("plan_create: x_out needs X_NORM / X_UNARY_MUL, 16-byte alignment and k % 4 == 0"); return MI355Q_ERR_ALIGN; }
+        {   // a plain store of this stage must not land on a plain operand the same stage still reads in other workgroups (ggml-alloc makes ADD in place)
+            auto overlaps = [](const float * a, int64_t na, const float * b, int64_t nb) { return a && b && a < b + nb && b < a + na; };
             VecSrc t0, t1; const bool r0 = resolve(in.x, in.k, in.x_id, t0), r1 = resolve(in.x1, in.k, in.x1_id, t1);
-            if ((r0 && t0.plain && overlaps(in.sum_out, in.k, in.x, in.k)) || (r1 && t1.plain && overlaps(in.sum_out, in.k, in.x1, in.k))) { mi355q_set_error("plan_create: sum_out overlaps a plain operand of the same stage"); return MI355Q_ERR_SHAPE; }
-        }
-        if (in.x_out) {
-            VecSrc t0, t1; const bool r0 = resolve(in.x, in.k, in.x_id, t0), r1 = resolve(in.x1, in.k, in.x1_id, t1);
-            if ((r0 && t0.plain && overlaps(in.x_out, in.k, in.x, in.k)) || (r1 && t1.plain && overlaps(in.x_out, in.k, in.x1, in.k))) { mi355q_set_error("plan_create: x_out overlaps a plain operand of the same stage"); return MI355Q_ERR_SHAPE; }
+            const bool p0 = r0 && t0.plain != nullptr, p1 = r1 && t1.plain != nullptr;
+            if (in.sum_out && !(in.flags & MI355Q_STAGE_NO_PLAIN) && ((p0 && overlaps(in.sum_out, in.k, in.x, in.k)) || (p1 && overlaps(in.sum_out, in.k, in.x1, in.k)))) { mi355q_set_error("plan_create: sum_out overlaps a plain operand of the same stage"); return MI355Q_ERR_SHAPE; }
+            if (in.x_out && ((p0 && overlaps(in.x_out, in.k, in.x, in.k)) || (p1 && overlaps(in.x_out, in.k, in.x1, in.k)))) { mi355q_set_error("plan_create: x_out overlaps a plain operand of the same stage"); return MI355Q_ERR_SHAPE; }
+            for (int i = 0; i < in.n_mats; ++i) if (!(in.flags & MI355Q_STAGE_NO_PLAIN) && ((p0 && overlaps(in.mats[i].y, in.mats[i].m, in.x, in.k)) || (p1 && overlaps(in.mats[i].y, in.mats[i].m, in.x1, in.k)))) { mi355q_set_error("plan_create: an output overlaps a plain operand of the same stage"); return MI355Q_ERR_SHAPE; }
         }
         const bool paired = in.y_kind == MI355Q_Y_UNARY_MUL;
         if (paired && (in.n_mats != 2 || in.mats[0].type != in.mats[1].type || in.mats[0].m != in.mats[1].m ||
@@ -1274,7 +1080,6 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
         if (in.y_kind != MI355Q_Y_ROWS && !paired) { mi355q_set_error("plan_create: unknown y_kind"); return MI355Q_ERR_UNSUPPORTED; }
         VecSrc x0, x1;
         if (!resolve(in.x, in.k, in.x_id, x0) || !resolve(in.x1, in.k, in.x1_id, x1)) { mi355q_set_error("plan_create: an activation operand straddles an earlier output"); return MI355Q_ERR_SHAPE; }
-        if ((x0.gran && (((uintptr_t) x0.gran - 1) & 1)) || (x1.gran && (((uintptr_t) x1.gran - 1) & 1))) { mi355q_set_error("plan_create: an operand starts at an odd element of an earlier output"); return MI355Q_ERR_ALIGN; }
         // the matrices of a stage share ONE quantized image of the activations: their types must pair with the same activation format
         for (int i = 1; i < in.n_mats; ++i)
             if (gemv_fast_family(in.mats[i].type) != gemv_fast_family(in.mats[0].type)) { mi355q_set_error("plan_create: the matrices of a stage must share the activation format (Q8_K or Q8_0 family)"); return MI355Q_ERR_UNSUPPORTED; }
@@ -1285,7 +1090,6 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             const int type = in.mats[i].type;
             const int fam = gemv_fast_family(type);
             if (fam < 0 || !(tbit(type) & SET_ANY) || !mi355q_weights_are_planar(type, in.k)) { mi355q_set_error("plan_create: weight type / k has no planar streaming kernel in the plan"); return MI355Q_ERR_UNSUPPORTED; }
-            const int64_t row_bytes = mi355q_row_size(type, in.k);
             PlanStage p = {};
             p.kind = PLAN_K_GEMV; p.tag_off = (unsigned) v.size() + 1;
             int64_t rows = 0; int n = 0;
@@ -1297,18 +1101,18 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 const mi355q_mat & m = in.mats[j];
                 if (!m.w || !m.y || m.m < 0) { mi355q_set_error("plan_create: null matrix pointer"); return MI355Q_ERR_SHAPE; }
                 if (((uintptr_t) m.w | (uintptr_t) m.w_stride) & 15) { mi355q_set_error("plan_create: planar rows must be 16-byte aligned"); return MI355Q_ERR_ALIGN; }
-                if (m.w_stride != row_bytes && m.m > 1) { mi355q_set_error("plan_create: the rows of a matrix must be contiguous (w_stride == row size): the loader copies whole row ranges"); return MI355Q_ERR_UNSUPPORTED; }
-                p.w[n] = (const uint8_t *) m.w; p.y[n] = m.y; p.row_begin[n] = (int) rows;
+                if (m.w_stride < mi355q_row_size(type, in.k)) { mi355q_set_error("plan_create: w_stride smaller than a row"); return MI355Q_ERR_SHAPE; }
+                p.w[n] = (const uint8_t *) m.w; p.y[n] = m.y; p.w_stride[n] = m.w_stride; p.row_begin[n] = (int) rows;
                 if (!paired || n == 0) {   // the stage's granules form one block indexed by concatenated row: matrix n starts at gran_count + rows
                     OutRange r = { m.y, m.m, sub_base + (size_t) rows, p.tag_off, in.y_id[j] };
                     outs.push_back(r);
                 }
-                rows += m.m; bytes += m.m * row_bytes; ++n;
+                rows += m.m; bytes += m.m * mi355q_row_size(type, in.k); ++n;
             }
             if (rows > 0x7FFFFFF0) { mi355q_set_error("plan_create: too many rows"); return MI355Q_ERR_UNSUPPORTED; }
-            gran_count += (size_t) ((rows + 3) & ~(int64_t) 3);
+            gran_count += (size_t) ((rows + 1) & ~(int64_t) 1);
             for (int j = n; j < GEMV_MAX_MATS; ++j) p.row_begin[j] = 0x7FFFFFFF;
-            p.total_rows = (int) rows; p.n_mats = n; p.type = type; p.k = (int) in.k; p.row_bytes = (int) row_bytes;
+            p.total_rows = (int) rows; p.n_mats = n; p.type = type; p.k = (int) in.k;
             p.x0 = x0; p.x1 = x1; p.x_kind = in.x_kind; p.x_unary = in.x_unary; p.eps = in.eps; p.norm_w = in.norm_w;
             // a fresh activation image at the head of a stage; sub-stages of other weight types continue on the same image
             const bool reuse = !first;
@@ -1319,49 +1123,41 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
                 p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off, in.sum_id) + 1);
             }
             if (first) p.x_out = in.x_out;
+            {   // one plain vector of whole 256-element spans: the direct gather + quantize form (MI355Q_PLAN_DIRECT=0 turns it off: A/B measurements)
+                static const bool no_direct = getenv("MI355Q_PLAN_DIRECT") && atoi(getenv("MI355Q_PLAN_DIRECT")) == 0;
+                if (first && !no_direct && in.x_kind == MI355Q_X_PLAIN && !in.x1 && in.k % 256 == 0) p.flags |= PLAN_F_DIRECT;
+            }
             if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;
+            p.prime = plan_depth(type);
             v.push_back(p); attn_of.push_back(-1);
             set |= tbit(type);
             const size_t colb = ((size_t) lds_col_bytes(fam, (int) in.k) + 15) & ~(size_t) 15;
-            if (colb > img_max) img_max = colb;
-            if ((size_t) row_bytes > row_max) row_max = (size_t) row_bytes;
+            if (colb > lds_max) lds_max = colb;
+            if ((size_t) in.k * 4 + 64 > stg_max) stg_max = (size_t) in.k * 4 + 64;
             first = false;
         }
     }
     if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
-    // LDS: [image | attention scratch][control block][row-slot terms][ring of np pages, a multiple of 4, 1024-aligned]
-    const size_t lds_cap = 160 * 1024 - 64;
-    const size_t ctl_off = (img_max + 63) & ~(size_t) 63;
-    const size_t ring_off = (ctl_off + CB_BYTES + PLAN_TERM_BYTES + 1023) & ~(size_t) 1023;
-    int np = ring_off + 16 * 1024 <= lds_cap ? (int) ((lds_cap - ring_off) / 4096) * 4 : 0;
-    if (const char * e = getenv("MI355Q_PLAN_RING_PAGES")) { const int want = atoi(e) & ~3; if (want >= 16 && want < np) np = want; }   // (dev: A/B of the ring size)
-    // the ring must hold a wave's item -- a row, or for a PAIRED stage both rows of a pair, 2 G rows apart -- with room to spare
-    if (np < 16 || (size_t) np * 1024 < 3 * row_max + 8192) { mi355q_set_error("plan_create: k / attention window too large: no room for the weight ring in LDS"); return MI355Q_ERR_UNSUPPORTED; }
-    for (auto & p : v) {
-        if (p.kind != PLAN_K_GEMV) continue;
-        int glog = 0;
-        if (p.flags & PLAN_F_PAIRED) while (glog < 5 && (size_t) 2 * ((size_t) 2 << glog) * (size_t) p.row_bytes <= (size_t) np * 1024 / 3) ++glog;   // largest G with 2 G rows <= a third of the ring
-        p.glog = glog;
-        p.kf = PLAN_K_GEMV | ((p.flags & 0xFF) << 8) | (glog << 24);
-    }
+    const size_t lds_total = lds_max + 64 + 8 * GEMV_WAVES + 1024 + ((stg_max + 15) & ~(size_t) 15);
+    if (lds_total > 160 * 1024 - 64) { mi355q_set_error("plan_create: k / attention window too large for the LDS staging area"); return MI355Q_ERR_UNSUPPORTED; }
+    if (const char * e = getenv("MI355Q_PLAN_PRIME")) { const int pr = atoi(e); for (auto & p : v) if (p.kind == PLAN_K_GEMV && pr >= 0 && pr < p.prime) p.prime = pr; }
 
     Plan * pl = new Plan();
-    pl->device = dev; pl->n_cu = n_cu; pl->n_stages = (int) v.size(); pl->set = set; pl->weight_bytes = bytes;
-    pl->ctl_off = (int) ctl_off; pl->ring_off = (int) ring_off; pl->np = np; pl->lds_total = ring_off + (size_t) np * 1024;
+    pl->device = dev; pl->n_cu = n_cu; pl->n_stages = (int) v.size(); pl->set = set; pl->lds_image = lds_max; pl->lds_total = lds_total; pl->weight_bytes = bytes;
     pl->even = (flags & MI355Q_FLAG_ROUND_EVEN) ? 1 : 0;
-    pl->gran_count = gran_count + 4;
-    pl->timeout_ticks = 100ull * 1000 * 20;                    // 20 ms of the 100 MHz real-time counter per wait
+    pl->gran_count = gran_count + 2;
+    pl->timeout_ticks = 100ull * 1000 * 20;                    // 20 ms of the 100 MHz real-time counter per poll
     if (const char * e = getenv("MI355Q_PLAN_TIMEOUT_MS")) pl->timeout_ticks = 100ull * 1000 * (unsigned long long) atoll(e);
     const void * kern = plan_kernel(set);
     if (!kern) { delete pl; mi355q_set_error("plan_create: this mix of weight types has no kernel instantiation"); return MI355Q_ERR_UNSUPPORTED; }
     int per_cu = 0;
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_cap) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GEMV_THREADS, pl->lds_total) != hipSuccess || per_cu < 1) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GEMV_THREADS, lds_total) != hipSuccess || per_cu < 1) {
         delete pl; mi355q_set_error("plan_create: persistent kernel does not fit a CU"); return MI355Q_ERR_HIP;
     }
-    pl->grid = n_cu;                                           // one workgroup per CU, all co-resident
+    pl->grid = n_cu;                                           // one workgroup per CU, all co-resident (checked again by the cooperative launch)
     bool ok = hipMalloc((void **) &pl->d_stages, v.size() * sizeof(PlanStage)) == hipSuccess &&
               hipMalloc((void **) &pl->d_sync, PLAN_SYNC_WORDS * sizeof(unsigned)) == hipSuccess &&
               hipMalloc((void **) &pl->d_gran, pl->gran_count * sizeof(Granule)) == hipSuccess &&
@@ -1376,6 +1172,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
             fixs(p.x0); fixs(p.x1); p.sum_gran = (Granule *) fix(p.sum_gran);
             p.yg = (Granule *) fix(p.yg);
             p.attn = attn_of[i] >= 0 ? pl->d_attn + attn_of[i] : nullptr;
+            p.next_attn = i + 1 < v.size() && attn_of[i + 1] >= 0 ? pl->d_attn + attn_of[i + 1] : nullptr;
         }
         ok = hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) == hipSuccess &&
              (va.empty() || hipMemcpy(pl->d_attn, va.data(), va.size() * sizeof(AttnStage), hipMemcpyHostToDevice) == hipSuccess) &&
@@ -1393,7 +1190,7 @@ int mi355q_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_st
     return MI355Q_OK;
 }
 
-int mi355q_plan_run(mi355q_plan * plan, void * stream) {
+int mi355q_regs_plan_run(mi355q_plan * plan, void * stream) {
     Plan * pl = (Plan *) plan;
     if (!pl) { mi355q_set_error("plan_run: null plan"); return MI355Q_ERR_SHAPE; }
     // tags = epoch + stage index + 1, epoch = run count * (stages + 1): never 0, never repeated until the 32-bit epoch wraps;
@@ -1406,37 +1203,33 @@ int mi355q_plan_run(mi355q_plan * plan, void * stream) {
     unsigned epoch = (unsigned) (pl->runs * span);
     ++pl->runs;
     const PlanStage * st = pl->d_stages; int n = pl->n_stages; unsigned * sync = pl->d_sync; int even = pl->even;
-    int ctl_off = pl->ctl_off, ring_off = pl->ring_off, np = pl->np;
-    unsigned ring_magic = (unsigned) (0x100000000ull / ((unsigned long long) np * 1024ull));
+    int image = (int) pl->lds_image;
     unsigned long long timeout = pl->timeout_ticks;
-    void * args[] = { (void *) &st, (void *) &n, (void *) &sync, (void *) &even, (void *) &timeout, (void *) &ctl_off, (void *) &ring_off, (void *) &np, (void *) &ring_magic, (void *) &epoch };
+    void * args[] = { (void *) &st, (void *) &n, (void *) &sync, (void *) &even, (void *) &timeout, (void *) &image, (void *) &epoch };
     // A PLAIN launch of one workgroup per CU (checked against the occupancy query at creation).  hipLaunchCooperativeKernel gives the same
     // residency and only adds a launch-time check of the grid size -- at +15-19 us of host time per launch, through a second (cooperative) HSA
     // queue whose teardown at process exit crashed inside the HSA runtime under rocprofv3 (MI355X_MICROARCH.md, coop-launch row).
-    // Every wait is bounded, so a workgroup that found no CU (another persistent kernel holding them) ends in status() == 1, not in a hang.
+    // Every poll is bounded, so a workgroup that found no CU (another persistent kernel holding them) ends in status() == 1, not in a hang.
     const hipError_t rc = hipLaunchKernel(plan_kernel(pl->set), dim3((unsigned) pl->grid), dim3(GEMV_THREADS), args, pl->lds_total, (hipStream_t) stream);
     if (rc != hipSuccess) { mi355q_set_error(hipGetErrorString(rc)); return MI355Q_ERR_HIP; }
     return MI355Q_OK;
 }
 
-/* dev / test hook: the number of runs the plan believes it has made (the epoch source); setting it close to the wrap exercises the granule reset */
-int mi355q_plan_debug_set_runs(mi355q_plan * plan, unsigned long long runs) {
+/* test hook: the number of runs the plan believes it has made (the epoch source); setting it close to the wrap exercises the granule reset */
+int mi355q_regs_plan_debug_set_runs(mi355q_plan * plan, unsigned long long runs) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_ERR_SHAPE;
     pl->runs = runs;
     return MI355Q_OK;
 }
-
-/* diagnostics: the plan's 32 sync words (word 0: abort flag; words 1..7 of an aborted plan: which wait gave up -- kind, stage, workgroup, wave, two operands,
- * landed pages).  Synchronizes with the device. */
-int mi355q_plan_debug_words(mi355q_plan * plan, unsigned * out32) {
+int mi355q_regs_plan_debug_words(mi355q_plan * plan, unsigned * out32) {
     Plan * pl = (Plan *) plan;
     if (!pl || !out32) return MI355Q_ERR_SHAPE;
     return hipMemcpy(out32, pl->d_sync, PLAN_SYNC_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? MI355Q_OK : MI355Q_ERR_HIP;
 }
 
-/* 0 = healthy; 1 = a wait timed out (the plan is dead: destroy it).  Synchronizes with the device. */
-int mi355q_plan_status(mi355q_plan * plan) {
+/* 0 = healthy; 1 = a poll timed out (the plan is dead: destroy it).  Synchronizes with the device. */
+int mi355q_regs_plan_status(mi355q_plan * plan) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_ERR_SHAPE;
     unsigned h[PLAN_SYNC_WORDS];
@@ -1444,17 +1237,17 @@ int mi355q_plan_status(mi355q_plan * plan) {
     return h[PLAN_SYNC_ABORT] ? 1 : 0;
 }
 
-int mi355q_plan_status_async(mi355q_plan * plan, unsigned * host_flag, void * stream) {
+int mi355q_regs_plan_status_async(mi355q_plan * plan, unsigned * host_flag, void * stream) {
     Plan * pl = (Plan *) plan;
     if (!pl || !host_flag) return MI355Q_ERR_SHAPE;
     if (hipMemcpyAsync(host_flag, pl->d_sync + PLAN_SYNC_ABORT, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t) stream) != hipSuccess) return MI355Q_ERR_HIP;
     return MI355Q_OK;
 }
 
-int64_t mi355q_plan_weight_bytes(const mi355q_plan * plan) { return plan ? ((const Plan *) plan)->weight_bytes : 0; }
-int     mi355q_plan_launch_stages(const mi355q_plan * plan) { return plan ? ((const Plan *) plan)->n_stages : 0; }
+int64_t mi355q_regs_plan_weight_bytes(const mi355q_plan * plan) { return plan ? ((const Plan *) plan)->weight_bytes : 0; }
+int     mi355q_regs_plan_launch_stages(const mi355q_plan * plan) { return plan ? ((const Plan *) plan)->n_stages : 0; }
 
-int mi355q_plan_destroy(mi355q_plan * plan) {
+int mi355q_regs_plan_destroy(mi355q_plan * plan) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_OK;
     (void) hipFree(pl->d_stages); (void) hipFree(pl->d_sync); (void) hipFree(pl->d_gran);

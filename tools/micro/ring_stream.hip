@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(1024) k_ring(const uint8_t * buf, unsigned byt
             }
             // groups I may issue now: group at page `issued` needs issued + 4 - tail <= np
             unsigned n = 0;
-            { unsigned p = issued; while (n < 2 && p < total_pages && p + 4 - tail <= (unsigned) np) { ++n; p += 4u * NL; } }
+            { unsigned p = issued; while (n < 2 && p < total_pages && (int) (p + 4 - tail) <= np) { ++n; p += 4u * NL; } }
             n = (unsigned) __builtin_amdgcn_readfirstlane((int) n);
             if (n == 0) {
                 if (landed != issued) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); landed = issued; if (lane == 0) lds_st(my_landed, landed); }
@@ -95,6 +95,8 @@ __global__ void __launch_bounds__(1024) k_ring(const uint8_t * buf, unsigned byt
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) lds_st(my_landed, 0x7FFFFFFFu);
+    } else if (WORK < 0) {                                       // the loader alone: consumers leave, the ring is never full
+        if (lane == 0) lds_st(ctl + 4 * (C_HEAD + wave), 0x7FFFFFFFu);
     } else {
         constexpr int NC = NCc;
         unsigned ring_off = (unsigned) wave * (unsigned) rb;   // (row * rb) % ring_bytes
@@ -163,13 +165,13 @@ static void run(const char * name, const uint8_t * d_buf, unsigned bytes_per_wg,
     std::vector<unsigned> got((size_t) grid * rows); unsigned fail = 0;
     hipMemcpy(got.data(), d_sums, got.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost);
     size_t bad = 0; for (size_t i = 0; i < got.size(); ++i) bad += got[i] != ref[i];
-    printf("%-34s rb %5d np %3d : %8.3f ms  %7.1f GB/s  %s (bad rows %zu, aborts %u)\n", name, rb, np, best, (double) grid * bytes_per_wg / best * 1e-6, bad || fail ? "WRONG" : "ok", bad, fail);
+    printf("%-34s rb %5d np %3d : %8.3f ms  %7.1f GB/s  %s (bad rows %zu, aborts %u)\n", name, rb, np, best, (double) grid * bytes_per_wg / best * 1e-6, WORK >= 0 && (bad || fail) ? "WRONG" : "ok", bad, fail);
     fflush(stdout);
 }
 
 int main() {
     const int grid = 256;
-    const unsigned rbs[] = { 2304, 8064, 3360 };
+    const unsigned rbs[] = { 2304 };
     for (unsigned rb : rbs) {
         // bytes per workgroup: a multiple of rb and of 1024, ~8 MB
         unsigned rows = (8u << 20) / rb; while ((rows * rb) % 4096u) --rows;
@@ -189,12 +191,9 @@ int main() {
             printf("plain 16-wave nt stream (%.0f MB)               : %8.3f ms  %7.1f GB/s\n", total * 1e-6, best, total / best * 1e-6);
         }
         run<32, true, 0, 1>("1 loader  D32 nt work0", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
-        run<48, true, 0, 1>("1 loader  D48 nt work0", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
-        run<24, true, 0, 2>("2 loaders D24 nt work0", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
-        run<32, true, 0, 2>("2 loaders D32 nt work0", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
-        run<32, false, 0, 2>("2 loaders D32 default work0", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
-        run<32, true, 48, 2>("2 loaders D32 nt work48", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
-        run<32, true, 96, 2>("2 loaders D32 nt work96", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
+        run<32, true, -1, 1>("1 loader  D32 nt ALONE", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
+        run<56, true, -1, 1>("1 loader  D56 nt ALONE", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
+        run<32, true, 48, 1>("1 loader  D32 nt work48", d_buf, bpw, rb, 120, d_sums, d_fail, ref, grid);
         hipFree(d_buf); hipFree(d_sums); hipFree(d_fail);
     }
     return 0;

@@ -23,7 +23,7 @@ act = torch.randn((1, cfg["n_embd"]), dtype=torch.float32, device=dev)
 plan = stage.make_decode_plan(cfg, act, 128, False)
 n = plan.launch_stages
 grid = 256
-buf = torch.zeros(n * grid * 2 * 8 + n * grid * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(n * grid * 2 * 8 + n * grid * 8 + n * grid * 16 * 4, dtype=torch.int64, device=dev)
 L.mi355q_debug_set_plan_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 stage.set_token(a.pos)
 for _ in range(3):
@@ -33,7 +33,8 @@ assert L.mi355q_debug_set_plan_stamps(buf.data_ptr(), n) == 0
 plan.run(); torch.cuda.synchronize()
 assert plan.status() == 0
 raw = buf.cpu().numpy()
-prof = raw[n * grid * 16:].reshape(n, grid, 8).astype(np.float64)
+prof = raw[n * grid * 16:n * grid * 24].reshape(n, grid, 8).astype(np.float64)
+pw = raw[n * grid * 24:].reshape(n, grid, 16, 4).astype(np.float64)
 s = raw[:n * grid * 16].reshape(n, grid, 2, 8).astype(np.float64)
 t0 = s[0, :, :, 0][s[0, :, :, 0] > 0].min()
 s = np.where(s > 0, (s - t0) / 100.0, np.nan)          # us
@@ -47,7 +48,16 @@ for st in range(n):
         line.append(f"[{i}] {np.nanmin(c0):7.2f}/{np.nanmedian(c0):7.2f}/{np.nanmax(c0):7.2f} | {np.nanmedian(c1):7.2f}")
     print("  ".join(line))
 
-print("step-loop cycle sums of wave 0 per stage (median over workgroups, shader cycles): bookkeeping | try next | arithmetic + term + arrive | row close | wait for next")
+print("step-loop cycle sums of wave 0 per stage (median over workgroups, shader cycles): bookkeeping | try next | arithmetic + terms + close | waiting for LANDED | waiting for a free SLOT || loader (cumulative): cycles reading the consumers' heads | cycles in s_waitcnt vmcnt | cycles issuing DMA")
 for st in range(n):
     if prof[st].sum() > 0:
-        print(f"stage {st:3d}  " + "  ".join(f"{np.median(prof[st, :, i]):9.0f}" for i in range(5)))
+        v = int(np.median(prof[st, :, 5]))
+        print(f"stage {st:3d}  " + "  ".join(f"{np.median(prof[st, :, i]):9.0f}" for i in range(5)) + f"  || tail {v >> 32} page {v & 0xFFFFFFFF}  blocked {np.median(prof[st, :, 6]):.0f}  tailread {np.median(prof[st, :, 7]):.0f}")
+
+print("per consumer wave (median over workgroups): arithmetic cycles | landed-wait cycles | other cycles | finished rows at (us)")
+for st in range(n):
+    if pw[st].sum() > 0:
+        fin = np.where(pw[st, :, :15, 2] > 0, (pw[st, :, :15, 2] - t0) / 100.0, np.nan)
+        print(f"stage {st:3d} arith " + " ".join(f"{np.median(pw[st, :, w, 0]):6.0f}" for w in range(15)))
+        print(f"          wait  " + " ".join(f"{np.median(pw[st, :, w, 1]):6.0f}" for w in range(15)))
+        print(f"          done  " + " ".join(f"{np.nanmedian(fin[:, w]):6.1f}" for w in range(15)))
