@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-fuse", action="store_true", help="one launch per matrix (no q/k/v, gate/up fusion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plugin", action="store_true", help="skip the whole-model leg through ggml_backend_graph_compute of the plugin")
+    ap.add_argument("--no-llama-bench", action="store_true", help="skip the leg that runs the reference's own llama-bench through the plugin and on the CPU backend")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="plumbing only (CPU/gloo test of the N>1 hop protocol): no GPU work")
     return ap.parse_args()
@@ -342,6 +343,53 @@ def plugin_graph_compute(seconds_cap=240):
     return out
 
 
+def llama_bench_leg(reps=2, threads=16, timeout_s=420):
+    """The metric's OWN harness: the reference's unmodified llama-bench (examples/llama-bench/llama-bench.cpp:1430-1468 test_prompt / test_gen, compiled
+    with libllama from the reference sources by oracle/Makefile into oracle/_ref/avx2) on a synthetic Llama-3-8B Q4_K_M GGUF (oracle/gguf_synth: exact
+    shapes and tensor-type mix, random weights, `no_vocab` tokenizer), pp512 + tg128: once with every layer on the plugin (-ngl 99, the plugin loaded
+    through GGML_BACKEND_PATH) and once on the reference CPU backend alone (-ngl 0, no plugin loaded), same binary, same box, same file, one after the
+    other.  A TIMER: it pins no parity (tests/ do).  Returns None where the harness is not built."""
+    import re, subprocess
+    ref = ROOT / "oracle" / "_ref" / "avx2"
+    exe, synth, plugin = ref / "llama-bench", ref / "gguf_synth", ROOT / "llama.cpp.dsp_amd" / "lib" / "libggml-mi355.so"
+    if not (exe.exists() and synth.exists() and plugin.exists()):
+        return None
+    gguf = Path(os.environ.get("TMPDIR", "/tmp")) / "mi355_llama3_8b_q4_k_m.synthetic.gguf"
+    if not gguf.exists():
+        r = subprocess.run([str(synth), "--preset", "8b", "--ftype", "q4_k_m", "--out", str(gguf)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "gguf_synth failed", "tail": (r.stdout + r.stderr)[-300:]}
+    def run(ngl, env, r_):
+        cmd = [str(exe), "-m", str(gguf), "-p", "512", "-n", "128", "-r", str(r_), "-ngl", str(ngl), "-t", str(threads), "-o", "json"]
+        pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        if pr.returncode != 0:
+            return None, pr
+        rows = json.loads(pr.stdout[pr.stdout.index("["):])
+        res = {}
+        for row in rows:
+            key = "pp512" if row["n_prompt"] else "tg128"
+            res[key] = {"value": round(row["avg_ts"], 2), "stddev": round(row["stddev_ts"], 2), "unit": "tok/s"}
+        res["backends"] = rows[0].get("backends"); res["model_type"] = rows[0].get("model_type"); res["model_size_bytes"] = rows[0].get("model_size")
+        return res, pr
+    env_gpu = dict(os.environ, GGML_BACKEND_PATH=str(plugin), MI355_GRAPH_STATS="1")
+    gpu, pr = run(99, env_gpu, reps)
+    out = {"harness": "oracle/_ref/avx2/llama-bench (the reference's llama-bench + libllama, unmodified sources) -p 512 -n 128", "model": "synthetic Llama-3-8B Q4_K_M GGUF (oracle/_ref/avx2/gguf_synth)",
+           "reps": reps}
+    if gpu is None:
+        out["ngl99"] = {"error": f"exit {pr.returncode}", "tail": (pr.stdout + pr.stderr)[-400:]}
+    else:
+        plans = re.findall(r"MI355 decode plans: (\d+) graph_compute calls ran as one persistent launch, (\d+) plans built", pr.stderr)
+        gpu["graph_compute_calls_as_one_launch"] = sum(int(a_) for a_, _ in plans) if plans else None      # expected: (reps + warm-up) x 128 + warm-up tokens
+        gpu["plans_built"] = sum(int(b_) for _, b_ in plans) if plans else None
+        out["ngl99"] = gpu
+    env_cpu = {k: v for k, v in os.environ.items() if k != "GGML_BACKEND_PATH"}
+    cpu, pr = run(0, env_cpu, 1)
+    out["ngl0_cpu"] = cpu if cpu is not None else {"error": f"exit {pr.returncode}", "tail": (pr.stdout + pr.stderr)[-400:]}
+    if cpu is not None:
+        out["ngl0_cpu"]["threads"] = threads
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -431,6 +479,9 @@ def main():
         act_out = torch.zeros_like(act)
         done = torch.zeros(1, dtype=torch.int32, device=device)
         tok = [0]
+        # llama_decode copies the token's logits to the host before llama_synchronize returns (src/llama-context.cpp: get_tensor_async of t_logits)
+        logits_dev = getattr(stage, "logits", None) if (plan is not None and rank == world - 1) else None
+        logits_host = torch.empty(logits_dev.shape, dtype=logits_dev.dtype, pin_memory=True) if logits_dev is not None else None
         def token():
             if world > 1 and rank > 0:
                 p2p_recv(act, rank - 1)                         # boundary activation from the previous stage: the first norm of this rank reads it
@@ -440,6 +491,8 @@ def main():
                 if world > 1 and rank < world - 1:
                     torch.add(stage.boundary[0], stage.boundary[1], out=act_out)       # the layer output h = ffn_inp + ffn_down
                     p2p_send(act_out, rank + 1)
+                if logits_host is not None:
+                    logits_host.copy_(logits_dev, non_blocking=True)
                 token_done(done)
                 torch.cuda.current_stream().synchronize()       # llama-bench: llama_decode + llama_synchronize per generated token
             else:
@@ -565,6 +618,7 @@ def main():
                            "whole_token_GBps": round(total_bytes * a.steps / dt / 1e9, 1) if world == 1 else None,
                            "measured_hbm_read_peak_GBps": measured_hbm_read_GBps(torch, device),   # this box, plain streaming read (guide: ~6.3 TB/s)
                            "all_kernels": all_kernels}
+        out["roofline"]["frac_of_measured"] = round(achieved / out["roofline"]["measured_hbm_read_peak_GBps"], 4)      # north_star's target (>= 0.70) is against THIS peak
         # ---- pp512: the same weights at N = 512 on the MFMA tier (second half of the north-star metric) ----
         if not a.no_pp and world == 1:
             Npp = 512
@@ -609,6 +663,18 @@ def main():
                     out["graph_compute"] = plugin_graph_compute()
                 except Exception as e:
                     out["graph_compute"] = {"error": repr(e)}
+            if plan is not None and a.ftype == "Q4_K_M" and not a.no_llama_bench:
+                try:
+                    out["llama_bench"] = llama_bench_leg()
+                except Exception as e:
+                    out["llama_bench"] = {"error": repr(e)}
+                lb = out.get("llama_bench") or {}
+                cpu_tg = ((lb.get("ngl0_cpu") or {}).get("tg128") or {}).get("value")
+                if cpu_tg:
+                    # BASELINE.md publishes no number for this metric on this hardware; what north_star names as the baseline is "the reference ggml CPU path
+                    # timed on the same box's host cores in the same llama-bench run": that tg128 figure, measured a minute ago by the same binary
+                    out["vs_baseline"] = round(out["value"] / cpu_tg, 2)
+                    out["vs_baseline_is"] = f"value / tg128 of the reference CPU backend in llama-bench on this box ({cpu_tg} tok/s, {lb['ngl0_cpu'].get('threads')} threads); BASELINE.md holds no published figure for MI355X"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

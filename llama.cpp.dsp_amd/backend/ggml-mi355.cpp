@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -50,7 +51,8 @@
 
 // ------------------------------------------------------------------------------------------------ contexts
 struct mi355_plan_entry {               // a decode plan cached per graph key (decode-plan.inc)
-    uint64_t key = 0;
+    uint64_t key = 0, key2 = 0;         // two independent 64-bit hashes of the node list; a hit needs both and the node count
+    int n_nodes = 0;
     mi355q_plan * plan = nullptr;
     std::vector<int> pre, post;         // node indices issued eagerly before / after the launch
     int n_stages = 0;
@@ -86,12 +88,15 @@ struct mi355_backend_ctx {
     void **     dest_table = nullptr;   // device array: destination base pointers of the CPY nodes (updated every compute)
     bool        dest_valid = false;     // the table holds THIS call's pointers (set by graph_compute after the upload, cleared on return)
     std::vector<void *> dest_host;
+    void **     dest_pinned = nullptr;  // pinned staging copy of the table: the per-token upload is one asynchronous copy from here
     bool        capturing = false;
     long        n_eager = 0, n_captured = 0, n_replayed = 0;   // graph_compute calls by how they ran (MI355_GRAPH_STATS=1 prints them)
     long        n_fused_norm = 0, n_fused_mats = 0, n_fused_act = 0, n_elided_cont = 0, n_fused_add = 0;   // launches saved by the fusions of mi355_issue_nodes
     // decode plans (decode-plan.inc): the N = 1 graph as one persistent launch, cached per graph key
     std::vector<struct mi355_plan_entry *> plans;
-    uint64_t    plan_declined_key = 0;
+    uint64_t    plan_declined[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int plan_declined_n = 0;   // graphs the matcher declined (alternating scheduler splits, MoE): not matched again
+    long        test_inject_abort = -1; // MI355_TEST_INJECT_PLAN_ABORT=N: the plugin raises the abort word itself after N planned calls (tests the recovery path)
+    double      t_phase[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; long n_timed = 0;   // MI355_TIMING=1: host microseconds of graph_compute by phase
     unsigned *  plan_abort = nullptr;   // pinned host word: != 0 once a plan's poll timed out
     bool        plans_disabled = false;
     long        n_planned = 0, n_plans_built = 0;
@@ -305,21 +310,41 @@ static void mi355_backend_free(ggml_backend_t backend) {
     if (getenv("MI355_GRAPH_STATS")) fprintf(stderr, "MI355 decode plans: %ld graph_compute calls ran as one persistent launch, %ld plans built\n", ctx->n_planned, ctx->n_plans_built);
     for (mi355_plan_entry * e : ctx->plans) { mi355q_plan_destroy(e->plan); delete e; }
     if (ctx->plan_abort) mi355q_host_free(ctx->plan_abort);
+    if (ctx->dest_pinned) mi355q_host_free(ctx->dest_pinned);
+    if (getenv("MI355_TIMING") && ctx->n_timed) {
+        static const char * names[8] = { "cpy dests + upload", "graph key", "plan lookup / compile", "prefix nodes", "plan launch", "status copy", "suffix nodes", "other paths" };
+        fprintf(stderr, "MI355 graph_compute host time over %ld planned calls (us per call):", ctx->n_timed);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f;", names[i], ctx->t_phase[i] / (double) ctx->n_timed);
+        fprintf(stderr, "\n");
+    }
     if (ctx->graph) mi355q_graph_destroy(ctx->graph);
     if (ctx->dest_table) mi355q_free(ctx->dest_table);
     delete ctx;
     delete backend;
 }
 
-static void mi355_check_plan_abort(mi355_backend_ctx * ctx) {
-    if (ctx->plan_abort && *ctx->plan_abort) GGML_ABORT("MI355: a decode plan timed out waiting for its producers (another persistent kernel holding CUs?); set MI355_NO_PLAN=1");
+// A decode plan whose polls timed out (another persistent kernel holding CUs, a reduced CU mask) raises its sticky abort word; the plugin reads it
+// into pinned memory behind every launch.  Recoverable-error convention of the reference (ggml-backend-impl.h:110: graph_compute returns a
+// ggml_status; only programming errors abort): the plans are destroyed, planning is switched off for this backend -- every later graph runs node by
+// node -- and the NEXT graph_compute returns GGML_STATUS_FAILED once, because the step that timed out has produced garbage the caller already holds
+// (llama_decode reports the failure; the application can decode that batch again).  The process is never aborted.
+static bool mi355_plan_aborted(mi355_backend_ctx * ctx) {
+    if (!ctx->plan_abort || !*ctx->plan_abort) return false;
+    GGML_LOG_ERROR("MI355: a decode plan timed out waiting for its producers (another persistent kernel holding CUs?): decode plans are now off for %s, "
+                   "the step that timed out is invalid; set MI355_NO_PLAN=1 to start without them\n", ctx->name.c_str());
+    (void) mi355q_stream_synchronize(ctx->stream);
+    for (mi355_plan_entry * e : ctx->plans) { mi355q_plan_destroy(e->plan); delete e; }
+    ctx->plans.clear();
+    ctx->plans_disabled = true;
+    *ctx->plan_abort = 0;
+    return true;
 }
 
 static void mi355_backend_synchronize(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
-    mi355_check_plan_abort(ctx);
+    // (a raised abort word is reported by the next graph_compute: synchronize has no status to return)
 }
 
 // ---- residency ops: thin wrappers over mi355q_op_* -- the tensor descriptor is ggml's ne[] / nb[] verbatim
@@ -413,12 +438,12 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int
 }
 
 // everything a captured launch / a decode plan depends on, EXCEPT the destination pointer of CPY nodes (read from dest_table on the device)
-static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph) {
-    uint64_t h = 1469598103934665603ull;
+static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph, uint64_t * second) {
+    uint64_t h = 1469598103934665603ull, h2 = 0x2545F4914F6CDD1Dull;
     // A token's graph is ~1000 nodes and this runs on every graph_compute: per node only what a launch can depend on is mixed in, a 64-bit word
     // at a time -- the node's op, parameters, type, shape, strides and address, and per operand its address, type and shape (an operand's strides
     // are those of its own node, or of a leaf whose address and shape fix them).
-    auto mix64 = [&](uint64_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
+    auto mix64 = [&](uint64_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h2 = (h2 + w) * 0xD6E8FEB86659FD93ull; h2 ^= h2 >> 32; };
     auto mix = [&](const void * p, size_t n) {
         const uint8_t * b = (const uint8_t *) p;
         for (; n >= 8; n -= 8, b += 8) { uint64_t w; memcpy(&w, b, 8); mix64(w); }
@@ -442,6 +467,7 @@ static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph) {
             if (!(cpy && j == 1)) mix64((uint64_t) (uintptr_t) t->data);
         }
     }
+    if (second) *second = h2;
     return h;
 }
 
@@ -668,56 +694,74 @@ static enum ggml_status mi355_issue_nodes(mi355_backend_ctx * ctx, struct ggml_c
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *) backend->context;
     mi355q_set_device(ctx->device);
-    mi355_check_plan_abort(ctx);
+    if (mi355_plan_aborted(ctx)) return GGML_STATUS_FAILED;
     static const bool env_off = getenv("MI355_NO_GRAPHS") != nullptr;
     static const bool env_no_plan = getenv("MI355_NO_PLAN") != nullptr;
+    static const bool timing = getenv("MI355_TIMING") != nullptr;
+    static const long inject = getenv("MI355_TEST_INJECT_PLAN_ABORT") ? atol(getenv("MI355_TEST_INJECT_PLAN_ABORT")) : -1;
     bool try_graphs = !env_off && !ctx->graphs_disabled && cgraph->n_nodes >= 8;
     const bool try_plan = !env_no_plan && !ctx->plans_disabled && cgraph->n_nodes >= 8;
     // (MUL_MAT_ID groups its rows by expert on the device at every size: such graphs are capturable too)
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = timing ? now_us() : 0.0, t_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    auto lap = [&](int i) { if (timing) { const double t = now_us(); t_acc[i] += t - t_mark; t_mark = t; } };
 
-    // destination pointers of the CPY nodes of THIS call
+    // destination pointers of the CPY nodes of THIS call: staged in pinned memory, uploaded by one asynchronous copy
     int n_cpy = 0;
     if (try_graphs || try_plan) {
-        ctx->dest_host.clear();
-        for (int i = 0; i < cgraph->n_nodes; ++i) if (cgraph->nodes[i]->op == GGML_OP_CPY && !ggml_is_empty(cgraph->nodes[i])) ctx->dest_host.push_back(cgraph->nodes[i]->data);
-        n_cpy = (int) ctx->dest_host.size();
+        if (!ctx->dest_pinned) MQ_CHECK(mi355q_host_malloc((void **) &ctx->dest_pinned, sizeof(void *) * MI355_MAX_CPY_DESTS));
+        for (int i = 0; i < cgraph->n_nodes; ++i) if (cgraph->nodes[i]->op == GGML_OP_CPY && !ggml_is_empty(cgraph->nodes[i])) {
+            if (n_cpy < MI355_MAX_CPY_DESTS) ctx->dest_pinned[n_cpy] = cgraph->nodes[i]->data;
+            ++n_cpy;
+        }
         if (n_cpy > MI355_MAX_CPY_DESTS) n_cpy = -1;
         else if (n_cpy > 0) {
             if (!ctx->dest_table) MQ_CHECK(mi355q_malloc((void **) &ctx->dest_table, sizeof(void *) * MI355_MAX_CPY_DESTS));
-            MQ_CHECK(mi355q_memcpy_h2d(ctx->dest_table, ctx->dest_host.data(), sizeof(void *) * n_cpy, ctx->stream));
+            MQ_CHECK(mi355q_memcpy_h2d(ctx->dest_table, ctx->dest_pinned, sizeof(void *) * n_cpy, ctx->stream));
         }
     }
     ctx->dest_valid = n_cpy > 0;
+    lap(0);
     enum ggml_status st = GGML_STATUS_SUCCESS;
     bool done = false;
-    uint64_t key = 0;
-    if ((try_graphs || try_plan) && n_cpy >= 0) key = mi355_graph_key(cgraph);
+    uint64_t key = 0, key2 = 0;
+    if ((try_graphs || try_plan) && n_cpy >= 0) key = mi355_graph_key(cgraph, &key2);
+    lap(1);
 
     // ---- the whole decode step as ONE persistent launch (decode-plan.inc), cached per graph key
     if (try_plan && n_cpy >= 0) {
         mi355_plan_entry * e = nullptr;
-        for (size_t i = 0; i < ctx->plans.size(); ++i) if (ctx->plans[i]->key == key) { e = ctx->plans[i]; if (i) std::swap(ctx->plans[i], ctx->plans[0]); break; }
-        if (!e && key != ctx->plan_declined_key) {
+        for (size_t i = 0; i < ctx->plans.size(); ++i) if (ctx->plans[i]->key == key && ctx->plans[i]->key2 == key2 && ctx->plans[i]->n_nodes == cgraph->n_nodes) { e = ctx->plans[i]; if (i) std::swap(ctx->plans[i], ctx->plans[0]); break; }
+        bool declined = false;
+        for (int i = 0; i < ctx->plan_declined_n; ++i) declined = declined || ctx->plan_declined[i] == key;
+        if (!e && !declined) {
             mi355_plan_entry * ne = new mi355_plan_entry();
             if (mi355_plan_compile(ctx, cgraph, *ne)) {
-                ne->key = key;
+                ne->key = key; ne->key2 = key2; ne->n_nodes = cgraph->n_nodes;
                 if (ctx->plans.size() >= 4) {                      // evict the least recently used plan (its launches must have finished)
                     MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
                     mi355q_plan_destroy(ctx->plans.back()->plan); delete ctx->plans.back(); ctx->plans.pop_back();
                 }
                 ctx->plans.insert(ctx->plans.begin(), ne);
                 e = ne; ++ctx->n_plans_built;
-            } else { delete ne; ctx->plan_declined_key = key; }
+            } else { delete ne; ctx->plan_declined[ctx->plan_declined_n < 8 ? ctx->plan_declined_n++ : (int) (key & 7)] = key; }
         }
+        lap(2);
         if (e) {
             if (!ctx->plan_abort) { MQ_CHECK(mi355q_host_malloc((void **) &ctx->plan_abort, 64)); *ctx->plan_abort = 0; }
             if (!e->pre.empty()) st = mi355_issue_nodes(ctx, cgraph, &e->pre);
+            lap(3);
             if (st == GGML_STATUS_SUCCESS) {
                 MQ_CHECK(mi355q_plan_run(e->plan, ctx->stream));
+                lap(4);
                 MQ_CHECK(mi355q_plan_status_async(e->plan, ctx->plan_abort, ctx->stream));
+                lap(5);
                 if (!e->post.empty()) st = mi355_issue_nodes(ctx, cgraph, &e->post);
+                lap(6);
             }
             done = true; ++ctx->n_planned;
+            if (inject >= 0 && ctx->n_planned == inject) { MQ_CHECK(mi355q_stream_synchronize(ctx->stream)); *ctx->plan_abort = 1; }      // (test hook: as if this launch had timed out)
+            if (timing) { for (int i = 0; i < 8; ++i) ctx->t_phase[i] += t_acc[i]; ++ctx->n_timed; }
         }
     }
 

@@ -1000,7 +1000,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
         bool overlapped = false;
         for (size_t i = outs.size(); i-- > 0;) {
             const OutRange & r = outs[i];
-            if (p >= r.p && p + n <= r.p + r.n) { take(r); return true; }
+            if (p >= r.p && p + n <= r.p + r.n) { if (r.gran_off == (size_t) -1) return false; take(r); return true; }      // (inside an x_out vector: stored plainly DURING the launch, not readable by a later stage)
             if (p < r.p + r.n && r.p < p + n) overlapped = true;
         }
         return !overlapped;                                    // a plain operand whose memory a stage of this plan overwrites: not expressible
@@ -1122,7 +1122,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
                 p.sum_plain = in.sum_out;
                 p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off, in.sum_id) + 1);
             }
-            if (first) p.x_out = in.x_out;
+            if (first) { p.x_out = in.x_out; if (in.x_out) { OutRange xr = { in.x_out, in.k, (size_t) -1, 0, -1 }; outs.push_back(xr); } }
             {   // one plain vector of whole 256-element spans: the direct gather + quantize form (MI355Q_PLAN_DIRECT=0 turns it off: A/B measurements)
                 static const bool no_direct = getenv("MI355Q_PLAN_DIRECT") && atoi(getenv("MI355Q_PLAN_DIRECT")) == 0;
                 if (first && !no_direct && in.x_kind == MI355Q_X_PLAIN && !in.x1 && in.k % 256 == 0) p.flags |= PLAN_F_DIRECT;

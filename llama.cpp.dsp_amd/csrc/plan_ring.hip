@@ -1393,7 +1393,7 @@ int mi355q_ring_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
         bool overlapped = false;
         for (size_t i = outs.size(); i-- > 0;) {
             const OutRange & r = outs[i];
-            if (p >= r.p && p + n <= r.p + r.n) { take(r); return true; }
+            if (p >= r.p && p + n <= r.p + r.n) { if (r.gran_off == (size_t) -1) return false; take(r); return true; }      // (inside an x_out vector: stored plainly DURING the launch, not readable by a later stage)
             if (p < r.p + r.n && r.p < p + n) overlapped = true;
         }
         return !overlapped;                                    // a plain operand whose memory a stage of this plan overwrites: not expressible
@@ -1520,7 +1520,7 @@ int mi355q_ring_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
                 p.sum_plain = in.sum_out;
                 p.sum_gran = (Granule *) (uintptr_t) (new_out(in.sum_out, in.k, p.tag_off, in.sum_id) + 1);
             }
-            if (first) p.x_out = in.x_out;
+            if (first) { p.x_out = in.x_out; if (in.x_out) { OutRange xr = { in.x_out, in.k, (size_t) -1, 0, -1 }; outs.push_back(xr); } }
             if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;

@@ -297,3 +297,43 @@ def test_plan_timeout_is_reported_not_hung(G, torch):
         assert plan.status() == 0
         assert np.array_equal(bits(y), bits(G.mul_mat(w, x)))
         plan.close()
+
+
+def test_epoch_wrap_resets_the_granules(G, torch):
+    """Tags are epoch + stage + 1 with epoch = run count x (stages + 1), 32 bits: before the product wraps, mi355q_plan_run zeroes the granules on the launch
+    stream and starts the count over.  The run counter is set just below the wrap (test hook mi355q_plan_debug_set_runs); the runs on both sides of the
+    reset must give the bit-identical chain outputs, and a stale tag of the old count must never satisfy a poll."""
+    rng = np.random.default_rng(77)
+    K = 2048
+    w1, w2 = W(G, oracle.Q4_K, K, K, rng), W(G, oracle.Q6_K, 512, K, rng)
+    x = dev(torch, rng.standard_normal((1, K)).astype(np.float32))
+    y1 = torch.zeros((1, K), dtype=torch.float32, device="cuda"); y2 = torch.zeros((1, 512), dtype=torch.float32, device="cuda")
+    plan = G.Plan([([w1], x, [y1], False), ([w2], y1, [y2], True)])
+    plan.run(); torch.cuda.synchronize()
+    ref1, ref2 = y1.clone(), y2.clone()
+    span = plan.launch_stages + 1
+    plan.debug_set_runs(0xFFFFFFFF // span - 3)
+    for _ in range(6):                                          # crosses the reset
+        y1.zero_(); y2.zero_()
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        assert np.array_equal(bits(y1), bits(ref1)) and np.array_equal(bits(y2), bits(ref2))
+    plan.close()
+
+
+def test_x_out_stores_the_formed_vector(G, torch):
+    """mi355q_stage.x_out (API version 3): an X_NORM stage also stores rms_norm(x0 + x1) * w as plain f32 -- bit-identical to mi355q_op_add_rms_norm_mul --
+    for a caller whose graph reads that vector besides the stage's matrices."""
+    rng = np.random.default_rng(78)
+    K = 4096
+    w = W(G, oracle.Q4_K, 256, K, rng)
+    x0 = dev(torch, rng.standard_normal((1, K)).astype(np.float32)); x1 = dev(torch, rng.standard_normal((1, K)).astype(np.float32))
+    nw = dev(torch, (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    y = torch.zeros((1, 256), dtype=torch.float32, device="cuda"); xo = torch.zeros((1, K), dtype=torch.float32, device="cuda"); so = torch.zeros((1, K), dtype=torch.float32, device="cuda")
+    plan = G.Plan([dict(ws=[w], ys=[y], x=x0, x1=x1, x_kind=G.X_NORM, norm_w=nw, eps=1e-5, sum_out=so, x_out=xo)])
+    plan.run(); torch.cuda.synchronize()
+    assert plan.status() == 0
+    r_x, r_sum = G.op_add_rms_norm_mul(x0, 1e-5, b=x1, weight=nw, want_sum=True)
+    assert np.array_equal(bits(xo), bits(r_x)) and np.array_equal(bits(so), bits(r_sum))
+    assert np.array_equal(bits(y), bits(G.mul_mat(w, r_x)))
+    plan.close()

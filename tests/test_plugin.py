@@ -226,6 +226,12 @@ def _run_model(args, env_extra=None, timeout=900):
     return subprocess.run([str(_model_parity())] + args, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+# Whole-model logits of two CORRECT evaluations differ by the chaos of re-quantized activations: the reference's own scalar and AVX2
+# builds by NMSE 2e-4 .. 5e-4 and 0.9 .. 1.6 % of max|logit| on these models.  The per-LAYER north-star bound (1e-3 / NMSE 1e-5) is asserted where chaos cannot
+# hide a bug: test_teacher_forced_layers.  The whole-model ceilings below are 2.5 x the measured spread (round 2 used 2e-3 / 8e-2).
+CHAOS_NMSE, CHAOS_REL = 1e-3, 4e-2
+
+
 def _planned(stderr):
     m = re.search(r"decode plans: (\d+) graph_compute calls ran as one persistent launch, (\d+) plans built", stderr)
     assert m, stderr[-2000:]
@@ -236,7 +242,8 @@ def _planned(stderr):
 @needs_plugin
 @pytest.mark.parametrize("model", ["l4", "l4_fa", "l1"])
 @pytest.mark.parametrize("plan", [True, False], ids=["plan", "node_by_node"])
-def test_whole_model_logits_against_cpu_fixture(model, plan):
+@pytest.mark.parametrize("ref_build", ["avx2", "scalar"])
+def test_whole_model_logits_against_cpu_fixture(model, plan, ref_build):
     """north_star's bar on LOGITS.  A synthetic llama model (n_embd 2048, n_vocab 32000, Q4_K_M types, seeded weights; 4 layers, 4 layers
     built the -fa way, 1 layer) is decoded for 16 tokens from an empty context on the plugin and every step's logits are compared with the
     committed fixture of the reference CPU backend (tests/golden/make_model_fixture.sh, AVX2 build).
@@ -249,8 +256,10 @@ def test_whole_model_logits_against_cpu_fixture(model, plan):
     step must have run as ONE persistent launch and the graph must stay resident (0 nodes refused)."""
     if _model_parity() is None or not _model_parity().exists():
         pytest.skip("oracle/_ref/*/model_parity not built")
-    fx = ROOT / "tests" / "golden" / f"model_logits_small_{model}.bin"
-    nz = ROOT / "tests" / "golden" / f"model_logits_small_{model}_scalar.bin"
+    # ref_build: which build of the reference made the fixture the plugin is held to (the other one gives the reference's own spread): the plugin's default
+    # rounding is the scalar spec's (roundf), so its distance from BOTH builds is reported
+    fx = ROOT / "tests" / "golden" / f"model_logits_small_{model}{'_scalar' if ref_build == 'scalar' else ''}.bin"
+    nz = ROOT / "tests" / "golden" / f"model_logits_small_{model}{'' if ref_build == 'scalar' else '_scalar'}.bin"
     args = ["--preset", "small", "--layers", "1" if model == "l1" else "4", "--vocab", "32000", "--tokens", "16", "--check", str(fx), "--noise", str(nz)]
     r = _run_model(args + (["--fa"] if model.endswith("fa") else []), None if plan else {"MI355_NO_PLAN": "1"})
     print(r.stdout[-3500:], r.stderr[-600:])
@@ -259,7 +268,7 @@ def test_whole_model_logits_against_cpu_fixture(model, plan):
     planned, built = _planned(r.stderr)
     assert (planned == 16 and 1 <= built <= 2) if plan else planned == 0, (planned, built)
     m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
-    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2            # (and in absolute terms never beyond the chaotic ceiling)
+    assert m and float(m.group(1)) <= CHAOS_NMSE and float(m.group(2)) <= CHAOS_REL            # (and in absolute terms never beyond the chaotic ceiling)
 
 
 @pytest.mark.gpu
@@ -275,7 +284,7 @@ def test_whole_model_decode_equal_to_cpu(mode):
     print(r.stdout[-2500:], r.stderr[-600:])
     # (no second reference build at hand in a live run: the chaotic ceiling of ~2 % of the logit scale is the bound here, see the fixture test)
     m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
-    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2, r.stdout[-3000:] + r.stderr[-2000:]
+    assert m and float(m.group(1)) <= CHAOS_NMSE and float(m.group(2)) <= CHAOS_REL, r.stdout[-3000:] + r.stderr[-2000:]
     assert "ARGMAX DIFFERS" not in r.stdout
     planned, _ = _planned(r.stderr)
     assert planned == (0 if mode == "no_plan" else 12)
@@ -295,7 +304,7 @@ def test_whole_model_other_weight_recipes(wtype, planned):
     r = _run_model(["--preset", "small", "--layers", "3", "--vocab", "8192", "--prompt", "40", "--tokens", "10", "--wtype", wtype])
     print(r.stdout[-2500:], r.stderr[-600:])
     m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
-    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2, r.stdout[-3000:] + r.stderr[-2000:]
+    assert m and float(m.group(1)) <= CHAOS_NMSE and float(m.group(2)) <= CHAOS_REL, r.stdout[-3000:] + r.stderr[-2000:]
     assert "ARGMAX DIFFERS" not in r.stdout and "0 refused by MI355_0" in r.stdout
     n_planned, _ = _planned(r.stderr)
     if planned is not None:
@@ -313,7 +322,7 @@ def test_whole_model_two_devices_through_the_scheduler():
     r = _run_model(["--preset", "small", "--layers", "4", "--vocab", "8192", "--tokens", "8", "--devs", "MI355_0,MI355_1", "--sched"], {"MI355_DUP_DEVICES": "2"})
     print(r.stdout[-2500:], r.stderr[-1200:])
     m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
-    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2, r.stdout[-3000:] + r.stderr[-2000:]
+    assert m and float(m.group(1)) <= CHAOS_NMSE and float(m.group(2)) <= CHAOS_REL, r.stdout[-3000:] + r.stderr[-2000:]
     assert "ARGMAX DIFFERS" not in r.stdout
     assert re.search(r"scheduler: 2 splits over 3 backends", r.stdout), r.stdout[-1500:]
     plans = re.findall(r"decode plans: (\d+) graph_compute calls ran as one persistent launch", r.stderr)
@@ -352,7 +361,61 @@ def test_moe_model_resident_and_equal_to_cpu():
     print(r.stdout[-2500:], r.stderr[-800:])
     assert "0 refused by MI355_0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
-    assert m and float(m.group(1)) <= 2e-3 and float(m.group(2)) <= 8e-2, r.stdout[-3000:]
+    assert m and float(m.group(1)) <= CHAOS_NMSE and float(m.group(2)) <= CHAOS_REL, r.stdout[-3000:]
     assert "ARGMAX DIFFERS" not in r.stdout
     g = re.search(r"graph_compute calls: (\d+) eager, (\d+) captured, (\d+) replayed", r.stderr)
     assert g and int(g.group(2)) >= 1 and int(g.group(3)) >= 3, r.stderr[-1500:]           # the MoE decode step is capturable: no host synchronize inside MUL_MAT_ID
+
+
+@pytest.mark.gpu
+@needs_plugin
+@pytest.mark.parametrize("plan", [True, False], ids=["plan", "node_by_node"])
+def test_teacher_forced_layers(plan):
+    """The north-star bound where chaos cannot hide a bug: after 4 ordinary decode steps, for 4 more tokens the reference CPU backend evaluates the whole
+    4-layer model keeping every layer's input and output; each layer ALONE is then evaluated through the plugin with the CPU's own input and KV cache of
+    that layer, and its output must equal the CPU's within NMSE 1e-5 and 1e-3 of max|ref| (5e-3 at worst, see below) (oracle/model_parity --teacher).  A layer is four matmul stages
+    and the attention: one re-quantization deep, so a systematic error of any stage shows, while the flipped-rounding noise of a 4-layer chain does not."""
+    if _model_parity() is None or not _model_parity().exists():
+        pytest.skip("oracle/_ref/*/model_parity not built")
+    for extra in ([], ["--fa"]):
+        r = _run_model(["--preset", "small", "--layers", "4", "--vocab", "8192", "--tokens", "4", "--teacher", "4"] + extra, None if plan else {"MI355_NO_PLAN": "1"})
+        print(r.stdout[-1500:], r.stderr[-400:])
+        assert "TEACHER-FORCED LAYERS OK" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
+        m = re.search(r"teacher-forced: .* worst NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
+        assert m and float(m.group(1)) <= 1e-5 and float(m.group(2)) <= 1e-3, r.stdout[-1500:]
+
+
+@pytest.mark.gpu
+@needs_plugin
+def test_result_norm_is_stored_by_the_plan(tmp_path):
+    """llama_context reads result_norm (the vector behind the output matrix) back as the embeddings, without an output flag on it.  The decode plan folds
+    that RMS_NORM * weight into the output stage's prologue; the matcher therefore asks the stage to ALSO store the formed vector (mi355q_stage.x_out).
+    Read back after every planned step it must equal what the node-by-node path leaves there."""
+    import numpy as np
+    if _model_parity() is None or not _model_parity().exists():
+        pytest.skip("oracle/_ref/*/model_parity not built")
+    outs = {}
+    for mode, env in (("plan", None), ("nodes", {"MI355_NO_PLAN": "1"})):
+        f = tmp_path / f"norm_{mode}.bin"
+        r = _run_model(["--preset", "small", "--layers", "2", "--vocab", "8192", "--tokens", "6", "--no-cpu", "--dump-norm", str(f)], env)
+        assert f.exists(), r.stdout[-2000:] + r.stderr[-1500:]
+        outs[mode] = np.fromfile(f, dtype=np.float32).reshape(6, -1)
+        planned, _ = _planned(r.stderr)
+        assert planned == (6 if mode == "plan" else 0)
+    a, b = outs["plan"], outs["nodes"]
+    assert np.isfinite(a).all() and np.abs(b).max() > 0
+    assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max(), float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.gpu
+@needs_plugin
+def test_plan_timeout_is_reported_not_fatal():
+    """A decode plan whose polls time out raises its abort word.  The plugin then destroys the plans, switches planning off for the backend and returns
+    GGML_STATUS_FAILED from the next graph_compute (ggml-backend-impl.h:110) -- it must not abort the process.  MI355_TEST_INJECT_PLAN_ABORT=3 raises the
+    word after the third planned step as a timed-out launch would."""
+    if _model_parity() is None or not _model_parity().exists():
+        pytest.skip("oracle/_ref/*/model_parity not built")
+    r = _run_model(["--preset", "small", "--layers", "2", "--vocab", "8192", "--tokens", "8", "--no-cpu"], {"MI355_TEST_INJECT_PLAN_ABORT": "3"})
+    print(r.stdout[-800:], r.stderr[-800:])
+    assert r.returncode > 0, r.returncode                          # a failed status reached the caller (negative = killed by a signal: the old GGML_ABORT)
+    assert "decode plans are now off" in r.stderr and "GGML_ABORT" not in r.stderr and "Aborted" not in r.stderr
