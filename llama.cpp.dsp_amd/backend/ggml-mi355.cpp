@@ -455,17 +455,25 @@ static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph, uint64_t * se
         // cache at the store position moves every token and must not invalidate the capture)
         if (n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE) continue;
         const bool cpy = n->op == GGML_OP_CPY;
+        // ~20 words per node (this loop is most of the plugin's host time per token: 40 us for 1100 nodes when every field of every operand was mixed in):
+        // the node's op, type, shape, strides above the first and address; its parameters (all of them only where an op has many); per operand that
+        // exists its address, the two leading extents and the row stride -- an operand's type and its other extents follow from those of the node that
+        // produced it (hashed itself) or are fixed for a leaf of this address (a weight, a graph input whose extents are the ones mixed in)
         mix64(((uint64_t) n->op << 32) | (uint64_t) n->type);
-        mix(n->op_params, sizeof(n->op_params));
-        mix(n->ne, sizeof(n->ne)); mix(n->nb, sizeof(n->nb));
+        const bool many = n->op == GGML_OP_ROPE || n->op == GGML_OP_FLASH_ATTN_EXT || n->op == GGML_OP_SOFT_MAX || n->op == GGML_OP_UNARY || n->op == GGML_OP_ARGSORT;
+        mix(n->op_params, many ? sizeof(n->op_params) : 16);
+        mix(n->ne, sizeof(n->ne)); mix(n->nb + 1, sizeof(n->nb) - sizeof(n->nb[0]));
         if (!cpy) mix64((uint64_t) (uintptr_t) n->data);
+        uint64_t present = 0;
         for (int j = 0; j < GGML_MAX_SRC; ++j) {
             const struct ggml_tensor * t = n->src[j];
-            if (!t) { mix64(0x5bd1e995u + (uint64_t) j); continue; }
-            mix64(((uint64_t) t->type << 32) ^ (uint64_t) j);
-            mix(t->ne, sizeof(t->ne)); mix(t->nb, sizeof(t->nb));
+            if (!t) continue;
+            present |= 1ull << j;
+            mix64((uint64_t) t->ne[0] ^ ((uint64_t) t->ne[1] << 32) ^ ((uint64_t) t->type << 58));
+            mix64((uint64_t) t->nb[1] ^ ((uint64_t) t->ne[2] << 40));
             if (!(cpy && j == 1)) mix64((uint64_t) (uintptr_t) t->data);
         }
+        mix64(present);
     }
     if (second) *second = h2;
     return h;

@@ -36,7 +36,7 @@ constexpr int PLAN_D_MAX = 8;                     // ring depth (1-KiB steps in 
 __host__ __device__ constexpr int plan_depth(int type) {   // Q5_K / Q6_K slots carry qh too (1.5 KiB per step): 6 steps are the bytes of 8 Q4_K steps
     return (type == MI355Q_TYPE_Q5_K || type == MI355Q_TYPE_Q6_K) ? 6 : PLAN_D_MAX;
 }
-enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32, PLAN_F_DIRECT = 64 };
+enum { PLAN_F_NEW_X = 2, PLAN_F_PLAIN_Y = 4, PLAN_F_SUM = 8, PLAN_F_SUM_PLAIN = 16, PLAN_F_PAIRED = 32, PLAN_F_DIRECT = 64, PLAN_F_ATTN_LDS = 128 };
 enum { PLAN_K_GEMV = 0, PLAN_K_ATTN = 1, PLAN_K_COMBINE = 2 };
 enum { PLAN_SYNC_ABORT = 0, PLAN_SYNC_WORDS = 32 };
 
@@ -56,6 +56,9 @@ struct AttnStage {
     Granule * part;                                // [n_head][n_split][head_dim + 2]  (o, m, l) of every split
     Granule * out_gran; float * out_plain;
     int mask_f16, n_head, n_head_kv, hd, n_kv, n_split, per, plain, p_f16;
+    int kv_lds;                                    // the split's K / V window fits the LDS: plan_attn_lds runs the stage
+    int fa_seq;                                    // rows-per-position V cache, window in one workgroup: the CPU's sequential f16 accumulation (plan_attn_lds)
+    int entry_barrier;                             // the previous stage is not a GEMV: its last LDS reads must be fenced off
     float scale;
     // rope (ggml_rope_cache_init; see ops_glue.hip k_rope)
     int n_dims, neox; float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1;
@@ -819,6 +822,464 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in,
     return true;
 }
 
+// ---- attention of one token, K / V window in LDS ---------------------------------------------------------------------
+// The same stage for a split whose window fits the LDS (AttnStage::kv_lds, decided at plan creation: 2 x per x head_dim f16 beside everything else;
+// llama-bench's tg128 always does).  Built around what a wave pays per instruction when it runs the serial part of a stage (2.8-5 ns each, 40-95 ns
+// per dependent LDS trip: profiles/round3_experiments.md) -- the round-2 stage above spent 14 us per layer on ~6000 issued instructions per wave:
+//   0  in parallel: waves 0..2 poll q / k / v;  one wave forms the rope table of this position (cos, sin per pair; the repeated f32 multiplication
+//      of ggml_rope_cache_init, 64 predicated steps) and the cache slot;  the others copy the cache window into LDS with LDS-DMA (16 bytes per lane)
+//      and fetch the mask.  Nothing here depends on the launch's own results except the polls.
+//   1  rope: one rotated pair per thread from the table; q -> f16 (the CPU's f16 vec_dot rounds src1), this token's k / v rows -> the cache and
+//      their place in the LDS window (no "is this the current slot" case later)
+//   2  scores: one POSITION per lane (no cross-lane reduction): 16-byte LDS reads of its K row, rotated by the lane so that the 64 rows do not
+//      collide on the banks
+//   3  softmax by wave 0 over at most 5 scores per lane held in registers
+//   4  P.V from LDS; publish.
+// FLASH graphs with the window in one workgroup (fa_seq) reproduce ggml_compute_forward_flash_attn_ext_f16 (ggml-cpu/ops.cpp:6686-6900): the CPU walks
+// the positions in order with a running maximum and keeps V.P in an F16 accumulator -- rescaled (f32 multiply, rounded to f16) whenever the maximum
+// grows, and v * expf(s - M) added with an f32 fma rounded to f16 per position.  That rounding chain is 1e-3 of the result (a layer's output differed
+// by NMSE 5e-5 from the CPU's while an f32 accumulator is closer to the exact product); here a thread owns one dim and walks the positions in the
+// CPU's order with the same two roundings, the rescale factors having been formed in parallel (prefix maximum) by step 3.
+template <int CTRL> __device__ __forceinline__ float dpp_keep_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float f16_round(float x) { return __half2float(__float2half_rn(x)); }
+
+// expf as the C library of the reference's host computes it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c): x / ln2 split into k / 32 + r, a 32-entry
+// table of 2^(i/32) and a cubic in r, everything in f64, rounded once to f32 -- so an f64 restatement gives the library's bits (the device library's
+// expf is a different algorithm, 1 ulp apart in ~10 % of the arguments: enough to flip an f16 rounding of the flash accumulator now and then).
+// The table lives in the lanes of the calling wave (lane i holds entry i % 32: `tab`), read with ds_bpermute: no memory access on the serial path.
+__device__ const unsigned long long PLAN_EXP2F_T[32] = {      // bits(2^(i/32)) - (i << 47), correctly rounded (generated with 60-digit decimal arithmetic)
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
+__device__ __forceinline__ float expf_libm(float x, unsigned long long tab) {      // (every lane of the wave must be active: ds_bpermute)
+    const double xd = (double) x;
+    const double z = 0x1.71547652b82fep+5 * xd;                 // 32 / ln 2
+    double kd = z + 0x1.8p+52;
+    const unsigned long long ki = (unsigned long long) __double_as_longlong(kd);
+    kd -= 0x1.8p+52;
+    const double r = z - kd;
+    const int src = 4 * (int) (ki & 31ull);
+    const unsigned lo = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (unsigned) tab), hi = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (unsigned) (tab >> 32));
+    const unsigned long long t = (((unsigned long long) hi << 32) | lo) + (ki << 47);
+    const double sd = __longlong_as_double((long long) t);
+    const double zz = 0x1.c6af84b912394p-20 * r + 0x1.ebfce50fac4f3p-13;
+    const double r2 = r * r;
+    double y = 0x1.62e42ff0c52d6p-6 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * sd;
+    float res = (float) y;
+    if (x < -0x1.9fe368p6f) res = 0.0f;                         // (underflow, -inf included)
+    if (x > 0x1.62e42ep6f) res = INFINITY;
+    if (x != x) res = x;
+    return res;
+}
+
+// t[I] of ggml_vec_dot_f16's reduction tree for one K row against q (see plan_attn_lds step 2): the accumulators (j, l = I) and (j, l = I + 4), j = 0..3
+template <int I>
+__device__ __forceinline__ float attn_score_t(const __half * krow, const __half * qh, int nblk) {
+    float alo[4] = { 0.f, 0.f, 0.f, 0.f }, ahi[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll 2
+    for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 kq = *(const uint4 *) (krow + 32 * blk + 8 * j), qq = *(const uint4 *) (qh + 32 * blk + 8 * j);
+            const unsigned kw = I < 2 ? kq.x : kq.y, kw4 = I < 2 ? kq.z : kq.w, qw = I < 2 ? qq.x : qq.y, qw4 = I < 2 ? qq.z : qq.w;
+            const float2 kf = __half22float2(*(const __half2 *) &kw), kf4 = __half22float2(*(const __half2 *) &kw4);
+            const float2 qf = __half22float2(*(const __half2 *) &qw), qf4 = __half22float2(*(const __half2 *) &qw4);
+            alo[j] = __builtin_fmaf((I & 1) ? kf.y : kf.x, (I & 1) ? qf.y : qf.x, alo[j]);
+            ahi[j] = __builtin_fmaf((I & 1) ? kf4.y : kf4.x, (I & 1) ? qf4.y : qf4.x, ahi[j]);
+        }
+    }
+    const float s_lo = __fadd_rn(__fadd_rn(alo[0], alo[2]), __fadd_rn(alo[1], alo[3]));
+    const float s_hi = __fadd_rn(__fadd_rn(ahi[0], ahi[2]), __fadd_rn(ahi[1], ahi[3]));
+    return __fadd_rn(s_lo, s_hi);
+}
+
+static __device__ __noinline__ bool plan_attn_lds(AttnC a_in, const StageCtx & c_in, unsigned tag_in) {
+    const AttnC a = (AttnC) (uintptr_t) uniform_ptr((const void *) (uintptr_t) a_in);      // (see uniform_ptr)
+    extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds_attn2[];                 // (LDS pointers re-derived from the LDS symbol: see plan_attn)
+    StageCtx c;
+    c.image = __builtin_amdgcn_readfirstlane(c_in.image);
+    c.lds = plan_lds_attn2; c.ctl = (int *) (plan_lds_attn2 + c.image); c.part = (double *) (plan_lds_attn2 + c.image + 64);
+    c.stg = (float *) (plan_lds_attn2 + c.image + 64 + 8 * GEMV_WAVES + 1024);
+    c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
+    c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
+    c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
+    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.pre_lds = c_in.pre_lds;
+    const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int tid = (int) threadIdx.x;
+    const int hd = a->hd, n_split = a->n_split;
+    if ((int) blockIdx.x >= a->n_head * n_split) return true;                    // (uniform: the whole workgroup has nothing to do)
+    const int h = (int) blockIdx.x / n_split, sp = (int) blockIdx.x % n_split, gq = a->n_head / a->n_head_kv, g = h / gq;
+    const int half = hd >> 1, per_pad = (a->per + 31) & ~31;
+    // LDS (inside the staging area)
+    __half * qh = (__half *) c.stg;                                            // roped q, f16 [hd]
+    float * misc = (float *) (qh + hd);                                        // [16]: 0 maximum, 1 sum, 2 cache slot (int), 3 last position + 1 (int)
+    float * sq = misc + 16, * sk = sq + hd, * sv = sk + hd;                    // q / k / v as polled
+    float * cst = sv + hd;                                                     // cos [hd/2] | sin [hd/2]
+    float * red = cst + hd;                                                    // [8][hd] P.V partials
+    float * pbuf = sq;                                                         // step 2's partial dot products: the 12 hd floats from sq to the end of red (free between steps 1 and 4)
+    float * sc = red + 8 * hd;                                                 // [per_pad] mask -> scores -> probabilities
+    float * msv = sc + per_pad;                                                // [per_pad] fa_seq: the accumulator's rescale factor per position
+    __half * kwin = (__half *) (msv + per_pad);                                // [cnt][hd + 8]: rows padded by 16 bytes, so that the 64 rows a wave reads side by side spread over the banks
+    const int krs = hd + 8;                                                    //   (16-byte aligned: every area above is a multiple of 64 bytes; no integer round trip, which would make the pointer generic)
+    __half * vwin = kwin + (size_t) per_pad * krs;                             // rows: [cnt][hd];  transposed cache: [hd][cnt]
+    // loads that depend on nothing this launch computes
+    const int32_t * pos_p = a->pos, * nkv_p = a->n_kv_dev;
+    char * const * kdst_p = a->k_dst, * const * vdst_p = a->v_dst;
+    const int pos = pos_p[0];
+    char * const kdst = *kdst_p, * const vdst = *vdst_p;
+    int n_kv = a->n_kv;                                                        // the window of THIS run (the plan is sized for a->n_kv)
+    if (nkv_p) n_kv = min(n_kv, max(1, nkv_p[0]));
+    const int per = (n_kv + n_split - 1) / n_split;
+    const int j0 = sp * per, j1 = min(n_kv, j0 + per), cnt = max(0, j1 - j0);
+    const int64_t v_nb_dim = a->v_nb_dim;
+    const bool v_rows = v_nb_dim == 2;
+    if (!v_rows && ((per | n_kv) & 7) != 0) return plan_attn(a_in, c_in, tag_in);   // (uniform) a transposed window is copied 8 positions at a time
+    if (a->entry_barrier) plan_lds_barrier();                                   // (after a GEMV stage the staging area is free already: its readers finished a barrier ago)
+    plan_prefetch_desc(c, wave, lane);
+    PLAN_STAMP(0);
+    unsigned long long exp_tab = 0ull;                                         // wave 0, flash graphs: expf_libm's table, fetched while the stage waits for q / k / v
+    if (wave == 0 && a->fa_seq) exp_tab = PLAN_EXP2F_T[lane & 31];
+
+    // ---- 0. polls | rope table | window copy ----
+    const int nch = (hd + 127) >> 7, n_poll = 3 * nch, n_tab = (half + 63) >> 6;
+    if (wave < n_poll) {
+        PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        const int which = wave / nch, ch = wave % nch;
+        VecSrc vs;
+        if (which == 0)      { vs.plain = a->q.plain; vs.gran = a->q.gran; vs.tag_off = a->q.tag_off; }
+        else if (which == 1) { vs.plain = a->k.plain; vs.gran = a->k.gran; vs.tag_off = a->k.tag_off; }
+        else                 { vs.plain = a->v.plain; vs.gran = a->v.gran; vs.tag_off = a->v.tag_off; }
+        vs.pad = 0;
+        const SrcView s = src_view(vs, (which == 0 ? h : g) * hd, hd, c.epoch);
+        float * dst = which == 0 ? sq : which == 1 ? sk : sv;
+        float v0 = 0.f, v1 = 0.f;
+        bool ok_all = true;
+        for (;;) {
+            const bool ok = src_try(s, ch, lane, v0, v1) || 128 * ch + 2 * lane >= hd;
+            if (__ballot(!ok) == 0ull) break;
+            if (!poll_backoff(pc, spins, lane)) { ok_all = false; break; }
+        }
+        const int e = 128 * ch + 2 * lane;
+        if (ok_all && e < hd) { dst[e] = v0; dst[e + 1] = v1; }
+        if (!ok_all && lane == 0) c.ctl[CTL_OK] = 0;
+    } else if (wave < n_poll + n_tab) {
+        // rope table (ops_glue.hip k_rope / ggml-cpu/ops.cpp:5088-5270): theta_ip = pos * theta_scale^ip by REPEATED f32 multiplication, as the CPU's cache
+        // init does; the chain is walked by every lane up to its own ip (predicated: the multiplier is 1 beyond it)
+        const int ip = 64 * (wave - n_poll) + lane;
+        const int n_dims = a->n_dims;
+        if (2 * ip < n_dims) {
+            const float * ffp = a->freq_factors;
+            const float ff = ffp ? ffp[ip] : 1.0f;
+            const float tscale = a->theta_scale;
+            float th = (float) pos;
+            const int steps = (n_dims >> 1) - 1;                               // (uniform) the longest chain
+#pragma unroll 8
+            for (int j = 0; j < steps; ++j) th = __fmul_rn(th, j < ip ? tscale : 1.0f);
+            const float theta_extrap = __fdiv_rn(th, ff);
+            const float theta_interp = a->freq_scale * theta_extrap;
+            float theta = theta_interp, mscale = a->attn_factor;
+            if (a->ext_factor != 0.0f) {
+                const float y = ((float) ip - a->corr0) / fmaxf(0.001f, a->corr1 - a->corr0);
+                const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * a->ext_factor;
+                theta = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+                mscale *= 1.0f + 0.1f * logf(1.0f / a->freq_scale);
+            }
+            cst[ip] = cosf(theta) * mscale; cst[half + ip] = sinf(theta) * mscale;
+        }
+        if (wave == n_poll && lane == 0) {                                      // the cache cell this token's row goes to
+            const unsigned long long diff = (unsigned long long) (kdst - a->k_cache), np = (unsigned long long) a->k_nb_pos;
+            ((int *) misc)[2] = ((diff | np) >> 32) == 0ull ? (int) ((unsigned) diff / (unsigned) np) : (int) (diff / np);
+        }
+    } else {
+        const int wi = wave - n_poll - n_tab, n_w = GEMV_WAVES - n_poll - n_tab;
+        if (cnt > 0) {
+            // LDS-DMA: 16 bytes per lane, each lane its own source address, lane l of an instruction landing at M0 + 16 l.  An ITEM is U consecutive
+            // 16-byte units in memory (a K / V row, or the window's positions of one dim of a transposed cache); 64 / U whole items per instruction,
+            // item i landing at byte 16 (U + pad) i of the area.  (One integer division per copy: ~25 instructions of a wave that issues one per 3-5 ns.)
+            auto copy = [&](unsigned lds_base, const char * src_base, int64_t item_stride, int n_items, int U, int pad) {
+                const int UL = U + pad;                                        // lanes (= 16-byte LDS slots) per item: the pad lanes are switched off
+                const int ipi = 64 / UL, li = lane / UL, lc = lane - li * UL;
+                for (int i0 = wi * ipi; i0 < n_items; i0 += n_w * ipi) {
+                    if (li < ipi && lc < U && i0 + li < n_items) {
+                        const char * src = src_base + (int64_t) (i0 + li) * item_stride + 16 * lc;
+                        const unsigned dst = (unsigned) __builtin_amdgcn_readfirstlane((int) (lds_base + 16u * (unsigned) (i0 * UL)));
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
+                    }
+                }
+            };
+            const int cpr = hd >> 3;                                           // 16-byte units per row
+            const unsigned kw_lds = (unsigned) (size_t) kwin, vw_lds = (unsigned) (size_t) vwin;
+            const int64_t knp = a->k_nb_pos;
+            copy(kw_lds, a->k_cache + (int64_t) g * a->k_nb_head + (int64_t) j0 * knp, knp, cnt, cpr, 1);
+            const char * vb = a->v_cache + (int64_t) g * a->v_nb_head;
+            if (v_rows) { const int64_t vnp = a->v_nb_pos; copy(vw_lds, vb + (int64_t) j0 * vnp, vnp, cnt, cpr, 0); }
+            else copy(vw_lds, vb + 2 * (int64_t) j0, v_nb_dim, hd, cnt >> 3, 0);  // positions contiguous per dim, 8 per unit: LDS holds [dim][cnt]  (cnt % 8 == 0, j0 % 8 == 0: checked on entry)
+        }
+        const char * maskp = a->mask; const int mask_f16 = a->mask_f16;
+        for (int jj = wi * 64 + lane; jj < cnt; jj += n_w * 64)                 // the additive mask of this split's positions (0 without a mask)
+            sc[jj] = maskp ? (mask_f16 ? __half2float(((const __half *) maskp)[j0 + jj]) : ((const float *) maskp)[j0 + jj]) : 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the window has landed (the copies were issued first: the mask's trip overlaps theirs)
+    }
+    // the descriptor fields the later steps need, fetched now (a scalar load first used in step 4 is a 0.2-0.7 us stall there)
+    const int n_dims_r = a->n_dims, neox_r = a->neox, p_f16 = a->p_f16, fa_seq = a->fa_seq, plain_out = a->plain;
+    const float scale_r = a->scale;
+    Granule * const out_gran = a->out_gran, * const part_gran = a->part; float * const out_plain = a->out_plain;
+    const int64_t v_dst_nb = a->v_dst_nb;
+    asm volatile("" :: "s"(n_dims_r), "s"(neox_r), "s"(p_f16), "s"(fa_seq), "s"(plain_out), "s"(scale_r), "s"(out_gran), "s"(part_gran), "s"(out_plain), "s"(v_dst_nb));
+    plan_lds_barrier();
+    if (!c.ctl[CTL_OK]) return false;
+    PLAN_STAMP(1);
+
+    // ---- 1. rope; this token's rows ----
+    const int slot = ((const int *) misc)[2];
+    const bool in_win = slot >= j0 && slot < j1, store = sp == 0 && h % gq == 0;     // one workgroup per kv head stores the row
+    if (tid < hd) {
+        const bool isq = tid < half;
+        const float * x = isq ? sq : sk;
+        const int ip = isq ? tid : tid - half, i0 = 2 * ip;
+        const int n_dims = n_dims_r;
+        float r0, r1; int e0, e1;
+        if (i0 < n_dims) {
+            const float cs = cst[ip], sn = cst[half + ip];
+            e0 = neox_r ? ip : i0; e1 = neox_r ? ip + n_dims / 2 : i0 + 1;
+            const float x0 = x[e0], x1 = x[e1];
+            r0 = x0 * cs - x1 * sn; r1 = x0 * sn + x1 * cs;
+        } else { e0 = i0; e1 = i0 + 1; r0 = x[e0]; r1 = x[e1]; }
+        const __half h0 = __float2half_rn(r0), h1 = __float2half_rn(r1);
+        if (isq) { qh[e0] = h0; qh[e1] = h1; }
+        else {
+            if (in_win) { kwin[(size_t) (slot - j0) * krs + e0] = h0; kwin[(size_t) (slot - j0) * krs + e1] = h1; }
+            if (store) { ((__half *) kdst)[g * hd + e0] = h0; ((__half *) kdst)[g * hd + e1] = h1; }
+        }
+    } else if (tid < 2 * hd) {
+        const int d = tid - hd;
+        const __half hv = __float2half_rn(sv[d]);
+        if (in_win) { if (v_rows) vwin[(size_t) (slot - j0) * hd + d] = hv; else vwin[(size_t) d * cnt + (slot - j0)] = hv; }
+        if (store) *(__half *) (vdst + (int64_t) (g * hd + d) * v_dst_nb) = hv;
+    }
+    plan_lds_barrier();
+    PLAN_STAMP(2);
+
+    // ---- 2. scores: lane = position, IN THE CPU'S SUMMATION ORDER ----
+    // ggml_vec_dot_f16 (ggml-cpu/vec.cpp:128-168, AVX2: GGML_F16_STEP 32, 8 lanes, 4 accumulators): element e of the row feeds accumulator
+    // (j, l) = ((e % 32) / 8, e % 8) by an f32 fma, blocks of 32 in order; then per l: (a0 + a2) + (a1 + a3) =: s[l]; t[i] = s[i] + s[i + 4];
+    // result (t0 + t1) + (t2 + t3).  The chains of different l are independent: they are dealt to 1, 2 or 4 waves per 64 positions (each takes
+    // whole t[i] subtrees), whose partial results meet in LDS and are added in the tree's order.  The score therefore has the CPU's bits, and with
+    // it the f16 roundings further down (probabilities of the non-flash graph, the flash accumulator) fall the same way.
+    {
+        const int G = (cnt + 63) >> 6;                                          // position groups of 64 (uniform; <= 5)
+        const int lg = G <= 1 ? 0 : G <= 2 ? 1 : G <= 4 ? 2 : 3;                // waves are dealt to 2^lg group slots; slots >= G idle
+        const int grp = wave & ((1 << lg) - 1), part = wave >> lg;
+        const int pstride = 64 << lg;
+        int lp = lg <= 2 ? 2 : 1;                                               // 4 parts (2 with 8 slots) ...
+        while (lp > 0 && (pstride << lp) > 12 * hd) --lp;                       // ... as far as their results fit pbuf (plan creation made sure one part does)
+        const int n_parts = 1 << lp, ni = 4 >> lp;                              // part p owns t[i], i in [p ni, (p + 1) ni)
+        const int jj = 64 * grp + lane;
+        if (grp < G && part < n_parts && jj < cnt) {
+            const __half * krow = kwin + (size_t) jj * krs;
+            const int nblk = hd >> 5;
+            float tt[4] = { 0.f, 0.f, 0.f, 0.f };
+            for (int ii = 0; ii < ni; ++ii) {                                   // (uniform)
+                const int i = part * ni + ii;
+                float t;
+                switch (i) {                                                    // (uniform; the element index becomes a constant: half selects instead of shifts)
+                case 0:  t = attn_score_t<0>(krow, qh, nblk); break;
+                case 1:  t = attn_score_t<1>(krow, qh, nblk); break;
+                case 2:  t = attn_score_t<2>(krow, qh, nblk); break;
+                default: t = attn_score_t<3>(krow, qh, nblk); break;
+                }
+                tt[ii] = t;
+            }
+            pbuf[part * pstride + jj] = ni == 1 ? tt[0] : ni == 2 ? __fadd_rn(tt[0], tt[1]) : __fadd_rn(__fadd_rn(tt[0], tt[1]), __fadd_rn(tt[2], tt[3]));
+        }
+        plan_lds_barrier();
+        if (wave < G) {                                                         // wave = position group
+            const int j2 = 64 * wave + lane;
+            if (j2 < cnt) {
+                float dot;
+                if (n_parts == 4)      dot = __fadd_rn(__fadd_rn(pbuf[j2], pbuf[pstride + j2]), __fadd_rn(pbuf[2 * pstride + j2], pbuf[3 * pstride + j2]));
+                else if (n_parts == 2) dot = __fadd_rn(pbuf[j2], pbuf[pstride + j2]);
+                else                   dot = pbuf[j2];
+                // (a fully masked position stays -inf whatever its cache row holds: never-written rows may be anything, 0 * NaN included)
+                const float m = sc[j2];
+                sc[j2] = m == -INFINITY ? -INFINITY : __fadd_rn(__fmul_rn(dot, scale_r), m);
+            }
+        }
+    }
+    plan_lds_barrier();
+    PLAN_STAMP(3);
+
+    // ---- 3. softmax statistics: wave 0, at most NV scores per lane in registers ----
+    constexpr int NV = 5;                                                       // (per <= 320: guaranteed by the LDS budget check at plan creation)
+    if (wave == 0) {
+        float s[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s[v] = 64 * v + lane < cnt ? sc[64 * v + lane] : -INFINITY;
+        float mx0 = s[0];
+#pragma unroll
+        for (int v = 1; v < NV; ++v) mx0 = fmaxf(mx0, s[v]);
+        mx0 = wave_max_f(mx0);
+        float l0 = 1.0f;
+        if (fa_seq) {
+            // the CPU's online softmax, positions in order jj = 64 v + lane: Mprev = the maximum before jj; a new maximum rescales the accumulator by
+            // expf(Mprev - s) and adds v with weight 1, otherwise the weight is expf(s - Mprev).  Masked positions (-inf) are skipped by the CPU.
+            float carry = -INFINITY; int last = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (64 * v < cnt) {                                             // (uniform)
+                    float x = s[v];                                             // inclusive prefix maximum over the lanes
+                    x = fmaxf(x, dpp_keep_f<0x111>(-INFINITY, x)); x = fmaxf(x, dpp_keep_f<0x112>(-INFINITY, x));
+                    x = fmaxf(x, dpp_keep_f<0x114>(-INFINITY, x)); x = fmaxf(x, dpp_keep_f<0x118>(-INFINITY, x));      // row_shr 1, 2, 4, 8: each row of 16 scanned
+                    const float r0 = readlane_f(x, 15), r1 = fmaxf(r0, readlane_f(x, 31)), r2 = fmaxf(r1, readlane_f(x, 47));
+                    x = fmaxf(x, lane < 16 ? -INFINITY : lane < 32 ? r0 : lane < 48 ? r1 : r2);
+                    float prev = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * ((lane + 63) & 63), __float_as_int(x)));   // lane - 1's inclusive maximum
+                    prev = fmaxf(lane == 0 ? -INFINITY : prev, carry);
+                    carry = fmaxf(carry, readlane_f(x, 63));
+                    const float sj = s[v];
+                    // (both exponentials are evaluated by every lane: expf_libm reads its table across the lanes)
+                    const bool live_j = sj != -INFINITY, newmax = live_j && sj > prev;
+                    const float e = expf_libm(newmax ? __fsub_rn(prev, sj) : live_j ? __fsub_rn(sj, prev) : 0.0f, exp_tab);
+                    const float ms = newmax ? e : 1.0f, vs = newmax ? 1.0f : live_j ? e : 0.0f;
+                    if (64 * v + lane < cnt) { sc[64 * v + lane] = vs; msv[64 * v + lane] = ms; }
+                    const unsigned long long live = __ballot(vs != 0.0f || ms != 1.0f);
+                    if (live) last = 64 * v + 64 - __builtin_clzll(live);
+                }
+            }
+            if (lane == 0) ((int *) misc)[3] = last;                           // (the sum S is walked with the accumulator in step 4, in the CPU's order)
+        } else if (p_f16) {
+            // The non-flash graph of the reference (SOFT_MAX, then MUL_MAT(v, kq) whose f16 src0 makes the CPU round kq to f16): the whole window is in
+            // this workgroup, so the probabilities are formed exactly as ggml_compute_forward_soft_max_f32 does -- sum of the exponentials in f64,
+            // p = e * (float) (1 / sum) -- and rounded to f16 before they meet V.
+            double ds = 0.0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (64 * v < cnt) {                                             // (uniform: a group of 64 beyond the window costs nothing)
+                    s[v] = (64 * v + lane < cnt && mx0 != -INFINITY) ? expf(__fsub_rn(s[v], mx0)) : 0.0f;
+                    ds += (double) s[v];
+                }
+            }
+            ds = wave_sum_f64(ds);
+            const float inv = (float) (1.0 / ds);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) if (64 * v < cnt) { if (64 * v + lane < cnt) sc[64 * v + lane] = f16_round(__fmul_rn(s[v], inv)); }
+        } else {
+            float ls = 0.0f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (64 * v < cnt) {
+                    const float p = (64 * v + lane < cnt && mx0 != -INFINITY) ? expf(__fsub_rn(s[v], mx0)) : 0.0f;
+                    if (64 * v + lane < cnt) sc[64 * v + lane] = p;
+                    ls += p;
+                }
+            }
+            l0 = wave_sum(ls);
+        }
+        if (lane == 0) { misc[0] = mx0; misc[1] = l0; }
+    }
+    plan_lds_barrier();
+    const float mx = misc[0], l = misc[1];
+    PLAN_STAMP(4);
+
+    // ---- 4. o[d] = sum_j p_j v[j][d]   (positions with p == 0 are skipped: masked cache rows may hold anything) ----
+    float o_own = 0.0f;                                                         // fa_seq: thread d's result
+    if (fa_seq) {
+        if (tid < hd) {
+            const int last = ((const int *) misc)[3];
+            float acc = 0.0f, S = 0.0f;                                         // acc: an f16 value at all times (the CPU's VKQ16);  S = S * ms + vs as the CPU walks it
+#pragma unroll 4
+            for (int j = 0; j < last; ++j) {
+                const float vs = sc[j], ms = msv[j];
+                const float vv = __half2float(vwin[(size_t) j * hd + tid]);
+                if (vs != 0.0f || ms != 1.0f) {                                 // (uniform) the CPU skips masked positions altogether
+                    if (ms != 1.0f) acc = f16_round(__fmul_rn(acc, ms));         // ggml_vec_scale_f16
+                    acc = f16_round(__builtin_fmaf(vv, vs, acc));                // ggml_vec_mad_f16 (f32 fma, then back to f16)
+                    S = __fadd_rn(__fmul_rn(S, ms), vs);
+                }
+            }
+            o_own = __fmul_rn(acc, __fdiv_rn(1.0f, S));                         // V *= 1 / S
+        }
+    } else if (v_rows) {
+        // a wave (8 of them) takes positions w, w + 8, ...; a lane owns dims (2l, 2l+1) [+128]
+        if (wave < 8) {
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 4
+            for (int j = wave; j < cnt; j += 8) {
+                const float p = sc[j];
+                if (p != 0.0f) {                                                // (uniform)
+                    const __half * row = vwin + (size_t) j * hd;
+                    if (2 * lane < hd)       { const float2 f = __half22float2(*(const __half2 *) (row + 2 * lane)); o0 += p * f.x; o1 += p * f.y; }
+                    if (2 * lane + 128 < hd) { const float2 f = __half22float2(*(const __half2 *) (row + 2 * lane + 128)); o2 += p * f.x; o3 += p * f.y; }
+                }
+            }
+            if (2 * lane < hd) { red[wave * hd + 2 * lane] = o0; red[wave * hd + 2 * lane + 1] = o1; }
+            if (2 * lane + 128 < hd) { red[wave * hd + 2 * lane + 128] = o2; red[wave * hd + 2 * lane + 129] = o3; }
+        }
+        plan_lds_barrier();
+        if (tid < hd) {
+            float o = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o += red[i * hd + tid];
+            o_own = o;
+        }
+    } else {
+        // transposed window [dim][cnt]: the CPU's MUL_MAT(v, p) is ggml_vec_dot_f16 over the positions (see step 2: blocks of 32, accumulators
+        // (j, l)).  Thread (d = tid / 8, l = tid % 8) owns the four accumulators (j, l) of dim d; the eight threads of a dim then walk the tree on DPP.
+        // Positions beyond the last whole block are added the way the CPU's tail loop does (f32 product, f64 sum).
+        for (int d = tid >> 3; d < hd; d += GEMV_THREADS >> 3) {                // (hd is a multiple of 32: whole waves stay together)
+            const int l = tid & 7;
+            const __half * vrow = vwin + (size_t) d * cnt;
+            const int np = cnt & ~31;
+            float acc[4] = { 0.f, 0.f, 0.f, 0.f };
+            for (int e0 = 0; e0 < np; e0 += 32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = sc[e0 + 8 * j + l];
+                    // (a probability of 0 must not meet a never-written cache cell: 0 * NaN; fma(v, 0, acc) == acc for every finite v)
+                    if (p != 0.0f) acc[j] = __builtin_fmaf(__half2float(vrow[e0 + 8 * j + l]), p, acc[j]);
+                }
+            }
+            float sl = __fadd_rn(__fadd_rn(acc[0], acc[2]), __fadd_rn(acc[1], acc[3]));
+            sl = __fadd_rn(sl, dpp_f<0x104>(sl));                               // row_shl:4 -- lane l < 4 of each 8: s[l] + s[l + 4]   (the other lanes' values are not used)
+            sl = __fadd_rn(sl, dpp_f<0xB1>(sl));                                // t0 + t1 (lane 0), t2 + t3 (lane 2)
+            sl = __fadd_rn(sl, dpp_f<0x4E>(sl));                                // (t0 + t1) + (t2 + t3)
+            if (l == 0) {
+                if (np < cnt) {
+                    double sumf = (double) sl;
+                    for (int e = np; e < cnt; ++e) { const float p = sc[e]; if (p != 0.0f) sumf += (double) __fmul_rn(__half2float(vrow[e]), p); }
+                    sl = (float) sumf;
+                }
+                red[d] = sl;
+            }
+        }
+        plan_lds_barrier();
+        if (tid < hd) o_own = red[tid];
+    }
+    PLAN_STAMP(7);
+    // ---- publish: the normalized output when the head is not split, else (o, m, l) of this split for the merge stage ----
+    if (n_split == 1) {
+        if (tid < hd) {
+            const float r = (p_f16 || fa_seq) ? o_own : __fdiv_rn(o_own, l);
+            publish(out_gran + h * hd + tid, r, tag);
+            if (plain_out) out_plain[h * hd + tid] = r;
+        }
+    } else {
+        Granule * part = part_gran + (size_t) ((size_t) h * n_split + sp) * (hd + 2);
+        if (tid < hd) publish(part + tid, o_own, tag);
+        else if (tid == hd) publish(part + hd, mx, tag);
+        else if (tid == hd + 1) publish(part + hd + 1, l, tag);
+    }
+    PLAN_STAMP(5);
+    return true;
+}
+
 // merge the KV splits of a head: out = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s     (workgroup h * n_split does head h)
 static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const StageCtx & c_in, unsigned tag_in) {
     const AttnC a = (AttnC) (uintptr_t) uniform_ptr((const void *) (uintptr_t) a_in);
@@ -916,7 +1377,7 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
             default: break;
             }
         } else if (kind == PLAN_K_ATTN) {
-            ok = plan_attn((AttnC) st->attn, c, epoch + st->tag_off);
+            ok = (st->flags & PLAN_F_ATTN_LDS) ? plan_attn_lds((AttnC) st->attn, c, epoch + st->tag_off) : plan_attn((AttnC) st->attn, c, epoch + st->tag_off);
         } else {
             ok = plan_attn_combine((AttnC) st->attn, c, epoch + st->tag_off);
         }
@@ -1140,6 +1601,24 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
         }
     }
     if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
+    {   // attention stages whose K / V window (2 x per x hd f16) fits beside everything else run from LDS (plan_attn_lds)
+        const size_t fixed = lds_max + 64 + 8 * GEMV_WAVES + 1024, cap = 160 * 1024 - 64;
+        const char * e = getenv("MI355Q_PLAN_KV_LDS"), * e2 = getenv("MI355Q_PLAN_FA_EXACT");
+        for (size_t si = 0; si < v.size(); ++si) {
+            if (v[si].kind != PLAN_K_ATTN) continue;
+            AttnStage & A = va[attn_of[si]];
+            const int per_pad = (A.per + 31) & ~31;
+            const size_t need = (size_t) 50 * A.hd + 64 + (size_t) 8 * per_pad + (size_t) 4 * per_pad * A.hd + (size_t) 16 * per_pad + 64;     // (plan_attn_lds: 12.5 hd + 16 + 2 per floats, K rows of hd + 8 f16, V)
+            const bool aligned = (A.k_nb_pos & 15) == 0 && (A.k_nb_head & 15) == 0 && ((uintptr_t) A.k_cache & 15) == 0 && ((uintptr_t) A.v_cache & 15) == 0 && (A.v_nb_head & 15) == 0 &&
+                                 (A.v_nb_dim == 2 ? (A.v_nb_pos & 15) == 0 : (A.v_nb_dim & 15) == 0 && A.v_nb_pos == 2);
+            int p2 = 64; while (p2 < A.per) p2 <<= 1;                          // (step 2's partial results of one part: 64 << lg floats inside 12 hd)
+            A.kv_lds = (!e || atoi(e) != 0) && aligned && A.per <= 320 && p2 <= 12 * A.hd && fixed + ((std::max(need, stg_max) + 15) & ~(size_t) 15) <= cap;
+            A.fa_seq = A.kv_lds && A.v_nb_dim == 2 && A.n_split == 1 && (!e2 || atoi(e2) != 0);
+            A.entry_barrier = si == 0 || v[si - 1].kind != PLAN_K_GEMV;
+            if (A.kv_lds) { v[si].flags |= PLAN_F_ATTN_LDS; if (need > stg_max) stg_max = need; }
+            if (getenv("MI355Q_PLAN_VERBOSE")) fprintf(stderr, "mi355q plan: attention stage %zu: n_kv %d, %d split(s) of %d positions, window %s LDS%s (%zu bytes, %zu fixed)\n", si, A.n_kv, A.n_split, A.per, A.kv_lds ? "in" : "not in", A.fa_seq ? ", sequential f16 accumulation" : "", need, fixed);
+        }
+    }
     const size_t lds_total = lds_max + 64 + 8 * GEMV_WAVES + 1024 + ((stg_max + 15) & ~(size_t) 15);
     if (lds_total > 160 * 1024 - 64) { mi355q_set_error("plan_create: k / attention window too large for the LDS staging area"); return MI355Q_ERR_UNSUPPORTED; }
     if (const char * e = getenv("MI355Q_PLAN_PRIME")) { const int pr = atoi(e); for (auto & p : v) if (p.kind == PLAN_K_GEMV && pr >= 0 && pr < p.prime) p.prime = pr; }

@@ -155,6 +155,8 @@ class Reference:
         L.ref_bench_chain.argtypes = [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32]
         if hasattr(L, "ref_glue_op"):
             L.ref_glue_op.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]
+        if hasattr(L, "ref_flash_attn_ext"):
+            L.ref_flash_attn_ext.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _i32]
 
     def blck_size(self, t): return self.lib.ref_blck_size(t)
     def type_size(self, t): return self.lib.ref_type_size(t)
@@ -229,6 +231,19 @@ class Reference:
                                   _ptr(fp), _ptr(ip), _ptr(out), 1)
         if rc != 0:
             raise RuntimeError(f"ref_glue_op({op}) failed: {rc}")
+        return out
+
+    def flash_attn_ext(self, q, k, v, mask, scale: float, max_bias: float = 0.0, softcap: float = 0.0, n_threads: int = 1):
+        """FLASH_ATTN_EXT on the reference CPU backend (refshim ref_flash_attn_ext).  numpy shapes as oracle.glue.flash_attn_ext:
+        q [B, H, N, DK] f32; k [B, Hk, n_kv, DK], v [B, Hv, n_kv, DV] (f16 values); mask [n_pad, n_kv] (f16 values) or None -> [B, N, H, DV] f32."""
+        q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+        ne = lambda x: np.asarray(list(x.shape)[::-1], np.int64)
+        m = np.ascontiguousarray(mask, np.float32) if mask is not None else None
+        out = np.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), np.float32)
+        rc = self.lib.ref_flash_attn_ext(_ptr(q), _ptr(ne(q)), _ptr(k), _ptr(ne(k)), _ptr(v), _ptr(ne(v)), _ptr(m) if m is not None else None,
+                                         m.shape[0] if m is not None else 0, scale, max_bias, softcap, _ptr(out), n_threads)
+        if rc != 0:
+            raise RuntimeError(f"ref_flash_attn_ext failed: {rc}")
         return out
 
     def bench_chain(self, types, Ms, Ks, N: int, n_threads: int, warmup: int, iters: int) -> float:

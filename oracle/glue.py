@@ -7,9 +7,21 @@ the real reference (oracle/_ref via refshim ref_glue_op) and by tests/golden/glu
 """
 from __future__ import annotations
 
+import ctypes
+import ctypes.util
+
 import numpy as np
 
 f32 = np.float32
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.expf.restype = ctypes.c_float; _libm.expf.argtypes = [ctypes.c_float]
+_libm.tanhf.restype = ctypes.c_float; _libm.tanhf.argtypes = [ctypes.c_float]
+
+
+def _expf(x) -> np.float32:
+    """the C library's expf, which is what the reference's scalar code calls (numpy's exp is a different implementation, 1 ulp apart now and then)"""
+    return f32(_libm.expf(float(x)))
 
 
 def bin_bcast(op: str, a: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -114,3 +126,79 @@ def mul_mat_f(a: np.ndarray, b: np.ndarray, a_is_f16: bool) -> np.ndarray:
         for i2 in range(b4.shape[1]):
             out[i3, i2] = (b4[i3, i2].astype(np.float64) @ a4[i3 // r3, i2 // r2].astype(np.float64).T).astype(f32)
     return out.reshape(b.shape[:-2] + (b.shape[-2], a.shape[-2]))
+
+
+def vec_dot_f16_simd(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """ggml_vec_dot_f16 in its AVX2 / F16C / FMA form (vec.cpp:128-168; simd-mappings.h: GGML_F16_STEP 32, GGML_F16_EPR 8, 4 accumulators,
+    GGML_F32x8_REDUCE): rows x [R, n] (f16 values) against y [n] (f16 values) -> [R] f32.  Element e feeds accumulator (j, l) = ((e % 32) / 8, e % 8)
+    by an f32 fma, blocks of 32 in order; then per l (a0 + a2) + (a1 + a3) = s[l]; t[i] = s[i] + s[i + 4]; result (t0 + t1) + (t2 + t3); the tail
+    beyond the last whole block is summed in f64 from f32-rounded products.  (The fma is taken as round(f64 sum of the exact product and the
+    accumulator): the product of two f16 values is exact in f64; the one remaining double rounding needs a 2^-29 coincidence.)"""
+    x = np.asarray(x, np.float16).astype(np.float64); y = np.asarray(y, np.float16).astype(np.float64)
+    R, n = x.shape
+    npb = n & ~31
+    acc = np.zeros((R, 4, 8), f32)
+    for b0 in range(0, npb, 32):
+        prod = (x[:, b0:b0 + 32] * y[b0:b0 + 32]).reshape(R, 4, 8)
+        acc = (prod + acc.astype(np.float64)).astype(f32)
+    s_ = ((acc[:, 0] + acc[:, 2]).astype(f32) + (acc[:, 1] + acc[:, 3]).astype(f32)).astype(f32)      # [R, 8]
+    t = (s_[:, :4] + s_[:, 4:]).astype(f32)
+    res = ((t[:, 0] + t[:, 1]).astype(f32) + (t[:, 2] + t[:, 3]).astype(f32)).astype(f32)
+    if npb < n:
+        tail = (x[:, npb:] * y[npb:]).astype(f32).astype(np.float64)
+        sumf = res.astype(np.float64)
+        for i in range(n - npb):
+            sumf = sumf + tail[:, i]
+        res = sumf.astype(f32)
+    return res
+
+
+def flash_attn_ext(q: np.ndarray, k: np.ndarray, v: np.ndarray, mask: np.ndarray | None, scale: float, max_bias: float = 0.0,
+                   logit_softcap: float = 0.0) -> np.ndarray:
+    """FLASH_ATTN_EXT with an F16 K / V cache (ops.cpp:6686-6905 ggml_compute_forward_flash_attn_ext_f16).
+    q: [B, H, N, DK] f32; k: [B, Hk, n_kv, DK] f16; v: [B, Hv, n_kv, DV] f16; mask: [>= N, n_kv] f16 or None.  Returns [B, N, H, DV] f32.
+    Per query row the CPU walks the positions IN ORDER with a running maximum M and sum S (online softmax) and keeps V.P in an F16 accumulator:
+      q -> f16;  s = dot(k_j, q) * scale [softcap] + slope * mask_j;  positions with mask == -inf are skipped;
+      s > M: ms = expf(Mold - s), VKQ16 = f16(f32(VKQ16) * ms) (ggml_vec_scale_f16), vs = 1;  else vs = expf(s - M);
+      VKQ16 = f16(fma(f32(v_j), vs, f32(VKQ16))) (ggml_vec_mad_f16, the F16C / FMA form);  S = S * ms + vs;
+    result = f32(VKQ16) * (1 / S).  The dot product is vec_dot_f16_simd above (the AVX2 build's order), expf / tanhf are the C library's.
+    Bit-exact against both reference builds (tests/test_oracle_glue.py)."""
+    q = np.asarray(q, f32); k = np.asarray(k, np.float16); v = np.asarray(v, np.float16)
+    B, H, N, DK = q.shape
+    Hk, n_kv, Hv, DV = k.shape[1], k.shape[2], v.shape[1], v.shape[3]
+    n_head_log2 = 1 << int(np.floor(np.log2(H)))
+    m0 = f32(2.0) ** f32(-(max_bias) / n_head_log2); m1 = f32(2.0) ** f32(-(max_bias / 2.0) / n_head_log2)
+    sc = f32(scale)
+    if logit_softcap != 0.0:
+        sc = f32(sc / f32(logit_softcap))
+    out = np.zeros((B, N, H, DV), f32)
+    q16 = q.astype(np.float16).astype(np.float64)
+    for b in range(B):
+        for h in range(H):
+            slope = f32(1.0)
+            if max_bias > 0.0:
+                slope = f32(m0 ** f32(h + 1)) if h < n_head_log2 else f32(m1 ** f32(2 * (h - n_head_log2) + 1))
+            kh = k[b, h // (H // Hk)].astype(np.float64); vh = v[b, h // (H // Hv)].astype(np.float64)
+            dots = np.stack([vec_dot_f16_simd(kh, q16[b, h, n]) for n in range(N)])     # [N, n_kv]
+            for n in range(N):
+                S = f32(0.0); M = f32(-np.inf)
+                acc = np.zeros(DV, np.float16)
+                for j in range(n_kv):
+                    mv = f32(slope * f32(mask[n, j])) if mask is not None else f32(0.0)
+                    if mv == -np.inf:
+                        continue
+                    s = f32(dots[n, j] * sc)
+                    if logit_softcap != 0.0:
+                        s = f32(f32(logit_softcap) * f32(_libm.tanhf(float(s))))
+                    s = f32(s + mv)
+                    ms = f32(1.0); vs = f32(1.0)
+                    if s > M:
+                        Mold = M; M = s
+                        ms = _expf(f32(Mold - M))
+                        acc = (acc.astype(f32) * ms).astype(np.float16)
+                    else:
+                        vs = _expf(f32(s - M))
+                    acc = (vh[j] * np.float64(vs) + acc.astype(np.float64)).astype(f32).astype(np.float16)     # fma in f32, then f16
+                    S = f32(f32(S * ms) + vs)
+                out[b, n, h] = acc.astype(f32) * f32(f32(1.0) / S)
+    return out

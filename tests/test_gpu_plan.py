@@ -217,7 +217,23 @@ def test_attention_stage(G, torch, layout, cfg):
         ref[h] = probs(Kg, q_r[h]) @ Vg
     got = out.cpu().numpy().reshape(n_head, hd).astype(np.float64)
     assert np.isfinite(got).all()
-    assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    # The flash layout with the whole window in one workgroup AND in LDS follows the CPU's FLASH_ATTN_EXT instead: positions in order, F16 accumulator
+    # (oracle/glue.py flash_attn_ext; 1e-3 away from the exact product).  Whether the window fits the LDS is the plan's decision, so either form passes
+    # here; test_attention_stage_follows_the_cpu_flash_accumulator pins the choice for the llama shape.
+    def seq_ref(K_, V_, q_, upto):
+        o = glue.flash_attn_ext(q_.astype(np.float32).reshape(1, n_head, 1, hd), K_[:upto].reshape(1, upto, n_head_kv, hd).transpose(0, 2, 1, 3),
+                                V_[:upto].reshape(1, upto, n_head_kv, hd).transpose(0, 2, 1, 3), None, scale)
+        return o.reshape(n_head, hd).astype(np.float64)
+    def check(got_, ref_, K_, V_, q_, upto, what):
+        err = np.abs(got_ - ref_).max() / np.abs(ref_).max()
+        if err <= tol:
+            return
+        assert layout == "rows_v" and n_kv <= 256, (what, err)
+        r2 = seq_ref(K_, V_, q_, upto)
+        d = np.abs(got_ - r2)
+        # (a score a few ulp from the oracle's can flip one f16 rounding of the accumulator: 2^-11 of it, in a few elements)
+        assert d.max() <= 2e-3 * np.abs(r2).max() and (d > 1e-6 * np.abs(r2).max()).mean() <= 0.05, (what, d.max() / np.abs(r2).max(), (d > 1e-6 * np.abs(r2).max()).mean())
+    check(got, ref, K_all, V_all, q_r, pos + 1, "first token")
     # a second token at pos + 1 through the SAME plan: only the device-side destination slots, pos and the mask move
     if pos + 1 < n_kv:
         pos2 = pos + 1
@@ -238,7 +254,7 @@ def test_attention_stage(G, torch, layout, cfg):
             Kg = K_all[:pos2 + 1, g * hd:(g + 1) * hd].astype(np.float64); Vg = V_all[:pos2 + 1, g * hd:(g + 1) * hd].astype(np.float64)
             ref2[h] = probs(Kg, q_r2[h]) @ Vg
         got2 = out.cpu().numpy().reshape(n_head, hd).astype(np.float64)
-        assert np.abs(got2 - ref2).max() <= tol * np.abs(ref2).max(), ("second token", np.abs(got2 - ref2).max() / np.abs(ref2).max())
+        check(got2, ref2, K_all, V_all, q_r2, pos2 + 1, "second token")
     plan.close()
 
 
@@ -279,6 +295,58 @@ def test_attention_stage_against_the_node_ops(G, torch):
     got = out.reshape(-1).cpu().numpy().astype(np.float64)
     assert ((got - ref) ** 2).sum() / (ref ** 2).sum() <= 1e-6
     plan.close()
+
+
+def test_attention_stage_follows_the_cpu_flash_accumulator(G, torch):
+    """Llama-3-8B's decode shape with the flash (rows per position) V cache and a window of 256: the stage runs from LDS and reproduces
+    ggml_compute_forward_flash_attn_ext_f16 -- positions in order, running maximum, F16 accumulator (ggml-cpu/ops.cpp:6810-6890; restated in
+    oracle/glue.py flash_attn_ext).  Nearly every element equals the oracle's to f32 rounding; the exact product is 1e-3 away.
+    MI355Q_PLAN_FA_EXACT=0 (read at plan creation) selects the f32 accumulator instead."""
+    import os
+    n_head, n_head_kv, hd, n_kv, pos = 32, 8, 128, 256, 201
+    rng = np.random.default_rng(77)
+    n_q, n_k, n_ctx = n_head * hd, n_head_kv * hd, 256
+    q = dev(torch, rng.standard_normal((1, n_q)).astype(np.float32)); k = dev(torch, rng.standard_normal((1, n_k)).astype(np.float32)); v = dev(torch, rng.standard_normal((1, n_k)).astype(np.float32))
+    kc_h = rng.standard_normal((n_ctx, n_k)).astype(np.float16); vc_h = rng.standard_normal((n_ctx, n_k)).astype(np.float16)
+    mask_h = np.full(n_kv, -np.inf, np.float16); mask_h[:pos + 1] = 0.0
+    scale = 1.0 / np.sqrt(hd)
+    posd = dev(torch, np.array([pos], np.int32))
+    w0 = W(G, oracle.Q4_K, 32, 256, rng); x0 = torch.zeros((1, 256), dtype=torch.float32, device="cuda"); y0 = torch.zeros((1, 32), dtype=torch.float32, device="cuda")
+    res = {}
+    for exact in ("1", "0"):
+        kc, vc = dev(torch, kc_h), dev(torch, vc_h)
+        out = torch.zeros((1, n_q), dtype=torch.float32, device="cuda")
+        dst = torch.tensor([kc.data_ptr() + pos * n_k * 2, vc.data_ptr() + pos * n_k * 2], dtype=torch.int64, device="cuda")
+        attn = dict(q=q, k=k, v=v, pos=posd, rope=dict(n_dims=hd, mode=0, n_ctx_orig=8192, freq_base=500000.0), k_cache=kc, v_cache=vc,
+                    k_nb_pos=n_k * 2, k_nb_head=hd * 2, v_nb_pos=n_k * 2, v_nb_dim=2, v_nb_head=hd * 2, k_dst=dst[0:1], v_dst=dst[1:2], v_dst_nb=2,
+                    mask=dev(torch, mask_h), n_head=n_head, n_head_kv=n_head_kv, head_dim=hd, n_kv=n_kv, scale=scale, out=out)
+        os.environ["MI355Q_PLAN_FA_EXACT"] = exact
+        try:
+            plan = G.Plan([([w0], x0, [y0], False), dict(attn=attn)])
+        finally:
+            del os.environ["MI355Q_PLAN_FA_EXACT"]
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        res[exact] = (out.reshape(n_head, hd).cpu().numpy().astype(np.float64), kc.cpu().numpy(), vc.cpu().numpy())
+        plan.close()
+    got, kc_a, vc_a = res["1"]
+    q_r = _rope_np(q.cpu().numpy().reshape(n_head, hd), pos, hd, 0, 500000.0)
+    K = kc_a[:pos + 1].reshape(1, pos + 1, n_head_kv, hd).transpose(0, 2, 1, 3); V = vc_a[:pos + 1].reshape(1, pos + 1, n_head_kv, hd).transpose(0, 2, 1, 3)
+    ref_seq = glue.flash_attn_ext(q_r.reshape(1, n_head, 1, hd), K, V, None, scale).reshape(n_head, hd).astype(np.float64)
+    qd = q_r.astype(np.float16).astype(np.float64)
+    ref_exact = np.zeros((n_head, hd))
+    for h in range(n_head):
+        g = h // (n_head // n_head_kv)
+        s_ = (K[0, g].astype(np.float64) @ qd[h]) * scale
+        p_ = np.exp(s_ - s_.max()); p_ /= p_.sum()
+        ref_exact[h] = p_ @ V[0, g].astype(np.float64)
+    top = np.abs(ref_seq).max()
+    d = np.abs(got - ref_seq)
+    assert d.max() <= 2e-3 * top and (d > 1e-6 * top).mean() <= 0.02, (d.max() / top, (d > 1e-6 * top).mean())
+    assert np.abs(got - ref_exact).max() > 1e-4 * top                       # the F16 accumulator is visible
+    got0 = res["0"][0]
+    assert np.abs(got0 - ref_exact).max() <= 2e-5 * top                     # the f32 accumulator: the exact product
+    assert np.array_equal(res["0"][1].view(np.uint16), kc_a.view(np.uint16)) and np.array_equal(res["0"][2].view(np.uint16), vc_a.view(np.uint16))
 
 
 def test_plan_timeout_is_reported_not_hung(G, torch):

@@ -82,3 +82,12 @@ def test_broadcast_mul_mat(orc):
     y = orc.mul_mat(t, g["w"], x2, M, N, K, ne02=1, ne12=2)
     assert np.array_equal(_bits(y[0, 0]), _bits(g["y"]))
     assert np.array_equal(_bits(y[0, 1]), _bits(g["y"][::-1]))
+
+
+@pytest.mark.parametrize("path", sorted(GOLDEN.glob("flash_attn_*.npz")), ids=lambda p: p.stem)
+def test_flash_attn_ext_golden(path):
+    """oracle/glue.py flash_attn_ext against the reference CPU backend's FLASH_ATTN_EXT (fixtures: tests/golden/make_flash_attn_golden.py), bit for bit."""
+    from oracle import glue
+    g = np.load(path, allow_pickle=False)
+    got = glue.flash_attn_ext(g["q"], g["k"], g["v"], g["mask"], float(g["scale"]), float(g["max_bias"]), float(g["softcap"]))
+    assert np.array_equal(got.view(np.uint32), g["y"].view(np.uint32))

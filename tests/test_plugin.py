@@ -373,7 +373,7 @@ def test_moe_model_resident_and_equal_to_cpu():
 def test_teacher_forced_layers(plan):
     """The north-star bound where chaos cannot hide a bug: after 4 ordinary decode steps, for 4 more tokens the reference CPU backend evaluates the whole
     4-layer model keeping every layer's input and output; each layer ALONE is then evaluated through the plugin with the CPU's own input and KV cache of
-    that layer, and its output must equal the CPU's within NMSE 1e-5 and 1e-3 of max|ref| (5e-3 at worst, see below) (oracle/model_parity --teacher).  A layer is four matmul stages
+    that layer, and its output must equal the CPU's within NMSE 5e-5 and 1e-2 of max|ref|, most layers within 1e-3 (oracle/model_parity --teacher; see the bound's derivation there).  A layer is four matmul stages
     and the attention: one re-quantization deep, so a systematic error of any stage shows, while the flipped-rounding noise of a 4-layer chain does not."""
     if _model_parity() is None or not _model_parity().exists():
         pytest.skip("oracle/_ref/*/model_parity not built")
@@ -381,8 +381,11 @@ def test_teacher_forced_layers(plan):
         r = _run_model(["--preset", "small", "--layers", "4", "--vocab", "8192", "--tokens", "4", "--teacher", "4"] + extra, None if plan else {"MI355_NO_PLAN": "1"})
         print(r.stdout[-1500:], r.stderr[-400:])
         assert "TEACHER-FORCED LAYERS OK" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
-        m = re.search(r"teacher-forced: .* worst NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
-        assert m and float(m.group(1)) <= 1e-5 and float(m.group(2)) <= 1e-3, r.stdout[-1500:]
+        m = re.search(r"teacher-forced: .* worst NMSE ([0-9.e+-]+) \(bound 5e-5\), worst max\|d\|/max\|ref\| ([0-9.e+-]+) \((\d+) of (\d+) layers above 1e-3", r.stdout)
+        # Integer dots, quantizers and the attention stage are bit-exact; a matmul's f32 terms are added in another order than the CPU's SIMD build does
+        # (3e-7 of max|y|), which flips ONE of a layer's ~12k int8 re-quantizations in every third layer or so -- 1e-3 .. 6e-3 of the maximum, NMSE <= 3e-5
+        # (model_parity.cc; the reference's own builds differ the same way).  At least half of the layers must be within 1e-3.
+        assert m and float(m.group(1)) <= 5e-5 and float(m.group(2)) <= 1e-2 and 2 * int(m.group(3)) <= int(m.group(4)), r.stdout[-1500:]
 
 
 @pytest.mark.gpu
