@@ -133,8 +133,8 @@ template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_Q6_K>(Chunk &
     const int j = lane & 7;
     ch.q  = ldg16_nt(row + 1024 * s + 16 * lane);
     ch.a  = ldg16_nt(row + 128 * nb + 512 * s + (64 * (lane >> 3) + 32 * (j >> 2) + 16 * (j & 1)));
-    ch.sc = *(const uint16_t *) (row + 192 * nb + 128 * s + 2 * lane);
-    ch.dh = *(const uint16_t *) (row + 208 * nb + 16 * s + 2 * (lane >> 3));
+    ch.sc = ldg<uint16_t>(row + 192 * nb + 128 * s + 2 * lane);
+    ch.dh = ldg<uint16_t>(row + 208 * nb + 16 * s + 2 * (lane >> 3));
 }
 template <int NCOLS> struct Consume<MI355Q_TYPE_Q6_K, NCOLS> {
     static __device__ __forceinline__ void run(const Chunk & ch, int s, int lane, const ActView * av, float * acc) {
@@ -165,7 +165,7 @@ template <int NCOLS> struct Consume<MI355Q_TYPE_Q6_K, NCOLS> {
 // ---- Q8_0 planar: [qs 32*nb][d 2*nb]; a chunk is HALF a block                      ggml-common.h:209-214
 template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_Q8_0>(Chunk & ch, const uint8_t * row, int nb, int s, int lane) {
     ch.q  = ldg16_nt(row + 1024 * s + 16 * lane);
-    ch.dh = *(const uint16_t *) (row + 32 * nb + 64 * s + 2 * (lane >> 1));
+    ch.dh = ldg<uint16_t>(row + 32 * nb + 64 * s + 2 * (lane >> 1));
 }
 template <int NCOLS> struct Consume<MI355Q_TYPE_Q8_0, NCOLS> {
     static __device__ __forceinline__ void run(const Chunk & ch, int s, int lane, const ActView * av, float * acc) {
@@ -184,7 +184,7 @@ template <int NCOLS> struct Consume<MI355Q_TYPE_Q8_0, NCOLS> {
 // ---- Q4_0 planar: [qs 16*nb][d 2*nb]; a chunk is one block                         ggml-common.h:167-172
 template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_Q4_0>(Chunk & ch, const uint8_t * row, int nb, int s, int lane) {
     ch.q  = ldg16_nt(row + 1024 * s + 16 * lane);
-    ch.dh = *(const uint16_t *) (row + 16 * nb + 128 * s + 2 * lane);
+    ch.dh = ldg<uint16_t>(row + 16 * nb + 128 * s + 2 * lane);
 }
 template <int NCOLS> struct Consume<MI355Q_TYPE_Q4_0, NCOLS> {
     static __device__ __forceinline__ void run(const Chunk & ch, int s, int lane, const ActView * av, float * acc) {
@@ -216,7 +216,7 @@ __device__ __forceinline__ uint32_t iq4_lut4(uint32_t nib) {
 // ---- IQ4_NL planar: [qs 16*nb][d 2*nb]; a chunk is one 32-block (low nibbles = elements 0..15, high = 16..31)      ggml-common.h block_iq4_nl
 template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_IQ4_NL>(Chunk & ch, const uint8_t * row, int nb, int s, int lane) {
     ch.q  = ldg16_nt(row + 1024 * s + 16 * lane);
-    ch.dh = *(const uint16_t *) (row + 16 * nb + 128 * s + 2 * lane);
+    ch.dh = ldg<uint16_t>(row + 16 * nb + 128 * s + 2 * lane);
 }
 template <int NCOLS> struct Consume<MI355Q_TYPE_IQ4_NL, NCOLS> {
     static __device__ __forceinline__ void run(const Chunk & ch, int s, int lane, const ActView * av, float * acc) {
@@ -237,7 +237,7 @@ template <int NCOLS> struct Consume<MI355Q_TYPE_IQ4_NL, NCOLS> {
 // ---- IQ4_XS planar: [qs 128*nb][hdr(d, scales_h, scales_l[4]) 8*nb]; a chunk is one 32-element sub-block            ggml-common.h block_iq4_xs
 template <> __device__ __forceinline__ void chunk_load<MI355Q_TYPE_IQ4_XS>(Chunk & ch, const uint8_t * row, int nb, int s, int lane) {
     ch.q = ldg16_nt(row + 1024 * s + 16 * lane);
-    const uint2 h = *(const uint2 *) (row + 128 * nb + 64 * s + 8 * (lane >> 3));
+    const uint2 h = ldg<uint2>(row + 128 * nb + 64 * s + 8 * (lane >> 3));
     ch.a.x = h.x; ch.a.y = h.y;
 }
 template <int NCOLS> struct Consume<MI355Q_TYPE_IQ4_XS, NCOLS> {

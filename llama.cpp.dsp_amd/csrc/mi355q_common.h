@@ -103,17 +103,26 @@ __device__ __forceinline__ int dot4(int a, int b, int c) {
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63); }
 
+// Loads of WEIGHT bytes name the global address space.  A pointer that arrives through a descriptor is generic to the compiler, and a generic
+// pointer costs a FLAT instruction: it may address LDS, so it counts on vmcnt AND lgkmcnt and can complete out of order with either queue -- with a
+// single flat access pending the compiler answers every dependency with s_waitcnt vmcnt(0) lgkmcnt(0).  In a software-pipelined stream (8 loads in
+// flight per wave, consumed one at a time) that waits for the load issued LAST before each step: the ring degenerates to depth 1.
+#define MI355Q_GLOBAL __attribute__((address_space(1)))
+typedef unsigned int mi355q_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mi355q_u2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ T ldg(const void * p) { return *(const MI355Q_GLOBAL T *) p; }
+template <> __device__ __forceinline__ uint2 ldg<uint2>(const void * p) { const mi355q_u2 v = *(const MI355Q_GLOBAL mi355q_u2 *) p; return make_uint2(v.x, v.y); }
 // 16-byte global load, non-temporal (weights are streamed exactly once: MI355X guide "nt-weights")
 __device__ __forceinline__ uint4 ldg16_nt(const void * p) {
-    const uint4 * q = (const uint4 *) p;
+    const MI355Q_GLOBAL unsigned int * q = (const MI355Q_GLOBAL unsigned int *) p;
     uint4 r;
-    r.x = __builtin_nontemporal_load(&q->x);
-    r.y = __builtin_nontemporal_load(&q->y);
-    r.z = __builtin_nontemporal_load(&q->z);
-    r.w = __builtin_nontemporal_load(&q->w);
+    r.x = __builtin_nontemporal_load(q);
+    r.y = __builtin_nontemporal_load(q + 1);
+    r.z = __builtin_nontemporal_load(q + 2);
+    r.w = __builtin_nontemporal_load(q + 3);
     return r;
 }
-__device__ __forceinline__ uint4 ldg16(const void * p) { return *(const uint4 *) p; }
+__device__ __forceinline__ uint4 ldg16(const void * p) { const mi355q_u4 v = *(const MI355Q_GLOBAL mi355q_u4 *) p; return make_uint4(v.x, v.y, v.z, v.w); }
 
 // ---- cross-lane reductions on DPP (VALU data-parallel primitives), not ds_bpermute: a 64-lane
 // __shfl_xor tree is ~6 dependent LDS-crossbar round trips (~0.4 us per reduction on gfx950).
@@ -144,6 +153,43 @@ __device__ __forceinline__ float oct_max(float v) {
 }
 // value of the neighbouring lane (lane ^ 1)
 __device__ __forceinline__ int pair_swap(int v) { return dpp_i<0xB1>(v); }
+
+// expf as the C library of the reference's host computes it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c): x / ln2 split into k / 32 + r, a 32-entry
+// table of 2^(i/32) and a cubic in r, everything in f64, rounded once to f32 -- so an f64 restatement gives the library's bits (the device library's
+// expf is a different algorithm, 1 ulp apart in ~10 % of the arguments: enough to flip an f16 rounding of the flash accumulator now and then).
+// The table lives in the lanes of the calling wave (lane i holds entry i % 32: `tab`), read with ds_bpermute: no memory access on the serial path.
+static __device__ const unsigned long long PLAN_EXP2F_T[32] = {      // bits(2^(i/32)) - (i << 47), correctly rounded (generated with 60-digit decimal arithmetic)
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
+__device__ __forceinline__ float expf_libm(float x, unsigned long long tab) {      // (every lane of the wave must be active: ds_bpermute)
+    const double xd = (double) x;
+    const double z = 0x1.71547652b82fep+5 * xd;                 // 32 / ln 2
+    double kd = z + 0x1.8p+52;
+    const unsigned long long ki = (unsigned long long) __double_as_longlong(kd);
+    kd -= 0x1.8p+52;
+    const double r = z - kd;
+    const int src = 4 * (int) (ki & 31ull);
+    const unsigned lo = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (unsigned) tab), hi = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (unsigned) (tab >> 32));
+    const unsigned long long t = (((unsigned long long) hi << 32) | lo) + (ki << 47);
+    const double sd = __longlong_as_double((long long) t);
+    const double zz = 0x1.c6af84b912394p-20 * r + 0x1.ebfce50fac4f3p-13;
+    const double r2 = r * r;
+    double y = 0x1.62e42ff0c52d6p-6 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * sd;
+    float res = (float) y;
+    if (x < -0x1.9fe368p6f) res = 0.0f;                         // (underflow, -inf included)
+    if (x > 0x1.62e42ep6f) res = INFINITY;
+    if (x != x) res = x;
+    return res;
+}
+
+// f32 -> f16 -> f32 of a value that was ROUNDED TO F32 FIRST.  Written plainly, fptrunc(fma(a, b, c)) is fused by the compiler into v_fma_mixlo_f16,
+// which rounds the exact a * b + c to f16 ONCE; the CPU rounds to f32 and then to f16, and the two differ whenever the f32 result lands on an f16 tie
+// (2^-13 of the operations: one or two elements of an attention output).  The empty asm pins the f32 value in a register between the two roundings.
+__device__ __forceinline__ float f16_round(float x) { asm volatile("" : "+v"(x)); return __half2float(__float2half_rn(x)); }
 
 // K-quant 6-bit (scale, min) pair j out of the 12-byte field given as three dwords
 // (get_scale_min_k4, ggml/src/ggml-quants.c:631-638)

@@ -124,7 +124,7 @@ template <> struct W32<MI355Q_TYPE_Q6_K> {          // planar [ql 128*nb][qh 64*
         const uint8_t * qh = row + 128 * (int64_t) nb + 64 * b + 32 * hh;
         h0 = ldg16(qh); h1 = ldg16(qh + 16);
         sc = ldg16(row + 192 * (int64_t) nb + 16 * b);
-        dh = *(const uint16_t *) (row + 208 * (int64_t) nb + 2 * b);
+        dh = ldg<uint16_t>(row + 208 * (int64_t) nb + 2 * b);
         s0 = 8 * hh + 4 * nib + 2 * sub; nsh = 4 * nib; fsh = 2 * (2 * nib + sub);
     }
     // scale of sub-block s (0..15) from the permuted 16-byte group (layout.hip: device byte 2j <- 8h+2cc+p, 2j+1 <- +4)
@@ -156,7 +156,7 @@ template <> struct W32<MI355Q_TYPE_Q8_0> {          // planar [qs 32*nb][d 2*nb]
         const int b = 2 * ks + sub;
         const uint8_t * p = row + 32 * (int64_t) b;
         q0 = ldg16_nt(p); q1 = ldg16_nt(p + 16);
-        dh = *(const uint16_t *) (row + 32 * (int64_t) nb + 2 * b);
+        dh = ldg<uint16_t>(row + 32 * (int64_t) nb + 2 * b);
     }
     __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_q8_0, ggml-quants.c:349-363
         const float d = h2f(dh);
@@ -172,7 +172,7 @@ template <> struct W32<MI355Q_TYPE_Q4_0> {          // planar [qs 16*nb][d 2*nb]
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
         const int b = 2 * ks + sub;
         q0 = ldg16_nt(row + 16 * (int64_t) b);
-        dh = *(const uint16_t *) (row + 16 * (int64_t) nb + 2 * b);
+        dh = ldg<uint16_t>(row + 16 * (int64_t) nb + 2 * b);
     }
     __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_q4_0, ggml-quants.c:255-273
         const float d = h2f(dh);
@@ -208,7 +208,7 @@ template <> struct W32<MI355Q_TYPE_IQ4_NL> {        // planar [qs 16*nb][d 2*nb]
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
         const int b = 2 * ks + sub;
         q0 = ldg16_nt(row + 16 * (int64_t) b);
-        dh = *(const uint16_t *) (row + 16 * (int64_t) nb + 2 * b);
+        dh = ldg<uint16_t>(row + 16 * (int64_t) nb + 2 * b);
     }
     __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_iq4_nl, ggml-quants.c:2436-2452: y = d * kvalues_iq4nl[nibble]
         const float d = h2f(dh);
@@ -226,7 +226,7 @@ template <> struct W32<MI355Q_TYPE_IQ4_XS> {        // planar [qs 128*nb][hdr 8*
     __device__ __forceinline__ void load(const uint8_t * row, int nb, int ks, int sub) {
         const int b = ks >> 2; ib = 2 * (ks & 3) + sub;
         q0 = ldg16_nt(row + 128 * (int64_t) b + 16 * ib);
-        h  = *(const uint2 *) (row + 128 * (int64_t) nb + 8 * b);
+        h  = ldg<uint2>(row + 128 * (int64_t) nb + 8 * b);
     }
     __device__ __forceinline__ void dequant(uint32_t * out) const {     // dequantize_row_iq4_xs, ggml-quants.c:2454-2475: dl = d * (ls - 32)
         const uint32_t scales_h = h.x >> 16;

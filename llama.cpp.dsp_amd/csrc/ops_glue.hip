@@ -476,8 +476,8 @@ __global__ void __launch_bounds__(256) k_mul_mat_f(const TensorD a, const Tensor
 constexpr int FA_THREADS = 1024, FA_WAVES = FA_THREADS / 64;      // 16 waves: a decode step has only n_head workgroups, each must hide its own latency
 __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, const TensorD k, const TensorD v, const TensorD m, int has_mask,
                                                         const TensorD d, float scale, float max_bias, float softcap, float m0, float m1, uint32_t n_head_log2,
-                                                        int n_split, float * __restrict__ part_out) {
-    extern __shared__ __attribute__((aligned(16))) float fa_s[];              // [n_kv] scores -> probabilities, then [256] partial sums
+                                                        int n_split, float * __restrict__ part_out, int seq) {
+    extern __shared__ __attribute__((aligned(16))) float fa_s[];              // [n_kv] scores -> probabilities, then [256] partial sums  (seq: + [n_kv] rescale factors)
     __shared__ float red[2 * FA_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // n_split > 1: the KV range is cut in n_split pieces, one workgroup each (a decode step has only n_head rows: more workgroups, shorter
@@ -507,19 +507,83 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
         for (int c = 0; c < JB; ++c) {
             const int64_t j = j0 + FA_WAVES * c;
             float s = 0.0f;
+            if (seq) {
+                // ggml_vec_dot_f16's order (vec.cpp:128-168, AVX2 form; see plan.hip plan_attn_lds step 2): element e = lane + 64 u feeds accumulator
+                // (jj, l) = ((e % 32) / 8, e % 8) of block e / 32 -- lanes L and L ^ 32 own the even and the odd blocks of one accumulator, whose chain
+                // therefore passes between the two halves of the wave; then the tree (a0 + a2) + (a1 + a3), s[l] + s[l + 4], (t0 + t1) + (t2 + t3).
+                const int nblk = (int) (DK >> 5), half = lane >> 5;
+                float acc = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s += kv[c][u] * qh[u];
+                for (int blk = 0; blk < 8; ++blk) {                       // (head sizes up to 256: 8 blocks; constant register indices)
+                    if (blk < nblk) {
+                        if (half == (blk & 1)) acc = __builtin_fmaf(kv[c][blk >> 1], qh[blk >> 1], acc);
+                        const float other = __shfl_xor(acc, 32, 64);
+                        if (half != (blk & 1)) acc = other;
+                    }
+                }
+                acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));            // (a0 + a2) in the j = 0 lanes, (a1 + a3) in the j = 1 lanes
+                acc = __fadd_rn(acc, __shfl_xor(acc, 8, 64));             // s[l]
+                acc = __fadd_rn(acc, __shfl_xor(acc, 4, 64));             // t[i] = s[i] + s[i + 4]
+                acc = __fadd_rn(acc, __shfl_xor(acc, 1, 64));             // t0 + t1 | t2 + t3
+                acc = __fadd_rn(acc, __shfl_xor(acc, 2, 64));
+                s = acc;                                                  // (lane 0)
+            } else {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                for (int u = 0; u < 4; ++u) s += kv[c][u] * qh[u];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            }
             if (lane == 0 && j < n_kv) {
-                s *= scale;
+                s = __fmul_rn(s, scale);
                 if (softcap != 0.0f) s = softcap * tanhf(s);
-                if (mp) s += slope * __half2float(mp[j]);
+                if (mp) {
+                    const float mv = __fmul_rn(slope, __half2float(mp[j]));
+                    s = (seq && mv == -INFINITY) ? -INFINITY : __fadd_rn(s, mv);     // (seq: a masked position is SKIPPED by the CPU whatever its cache row holds)
+                }
                 fa_s[j] = s;
             }
         }
     }
     __syncthreads();
+    if (seq) {
+        // ---- the CPU's online softmax with its F16 accumulator (ggml-cpu/ops.cpp:6810-6890; plan.hip plan_attn_lds steps 3 and 4; oracle/glue.py
+        // flash_attn_ext).  Wave 0 walks the scores 64 at a time: prefix maximum -> per position the accumulator's rescale factor ms and the weight vs.
+        float * msv = fa_s + n_kv;
+        if (wave == 0) {
+            const unsigned long long tab = PLAN_EXP2F_T[lane & 31];
+            float carry = -INFINITY;
+            for (int64_t j0 = 0; j0 < n_kv; j0 += 64) {
+                const int64_t j = j0 + lane;
+                const float sj = j < n_kv ? fa_s[j] : -INFINITY;
+                float x = sj;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(x, off, 64); if (lane >= off) x = fmaxf(x, o); }     // inclusive prefix maximum
+                float prev = __shfl_up(x, 1, 64);
+                prev = fmaxf(lane == 0 ? -INFINITY : prev, carry);
+                carry = fmaxf(carry, __shfl(x, 63, 64));
+                const bool live = sj != -INFINITY, newmax = live && sj > prev;
+                const float e = expf_libm(newmax ? __fsub_rn(prev, sj) : live ? __fsub_rn(sj, prev) : 0.0f, tab);
+                if (j < n_kv) { fa_s[j] = newmax ? 1.0f : live ? e : 0.0f; msv[j] = newmax ? e : 1.0f; }
+            }
+        }
+        __syncthreads();
+        if (tid < DV) {
+            const char * vb = v.data + j_lo * v.nb[1] + hv * v.nb[2] + bv * v.nb[3] + 2 * (int64_t) tid;
+            float acc = 0.0f, S = 0.0f;                                    // acc: an f16 value at all times (VKQ16)
+#pragma unroll 4
+            for (int64_t j = 0; j < n_kv; ++j) {
+                const float vs = fa_s[j], ms = msv[j];
+                if (vs != 0.0f || ms != 1.0f) {                             // (uniform) masked positions are skipped altogether
+                    const float vv = __half2float(*(const __half *) (vb + j * v.nb[1]));
+                    if (ms != 1.0f) acc = f16_round(__fmul_rn(acc, ms));         // ggml_vec_scale_f16
+                    acc = f16_round(__builtin_fmaf(vv, vs, acc));                // ggml_vec_mad_f16
+                    S = __fadd_rn(__fmul_rn(S, ms), vs);
+                }
+            }
+            *(float *) (d.data + tid * d.nb[0] + h * d.nb[1] + t * d.nb[2] + b * d.nb[3]) = __fmul_rn(acc, __fdiv_rn(1.0f, S));
+        }
+        return;
+    }
     // ---- row maximum, exponentials, their sum
     float mx = -INFINITY;
     for (int64_t j = tid; j < n_kv; j += FA_THREADS) mx = fmaxf(mx, fa_s[j]);
@@ -1032,12 +1096,16 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
             OPS_LAUNCHED();
         }
     }
-    // few rows (decode): split the KV range so that the chip is not left to n_head workgroups with long dependent chains
+    // few rows (decode): split the KV range so that the chip is not left to n_head workgroups with long dependent chains -- unless the window is short
+    // enough for ONE workgroup per row to follow the CPU's sequential F16 accumulation (k_flash_attn_ext, seq): then the result has the CPU's bits
+    // (MI355Q_FA_EXACT=0 keeps the f32 form)
+    static const bool fa_exact = !(getenv("MI355Q_FA_EXACT") && atoi(getenv("MI355Q_FA_EXACT")) == 0);
+    const int seq = fa_exact && n_kv <= 1024 && DK % 32 == 0 ? 1 : 0;
     int n_split = 1;
-    if (N * n_head * nb3 <= 256 && n_kv >= 256) { n_split = (int) ((n_kv + 127) / 128); if (n_split > 8) n_split = 8; }
+    if (!seq && N * n_head * nb3 <= 256 && n_kv >= 256) { n_split = (int) ((n_kv + 127) / 128); if (n_split > 8) n_split = 8; }
     if (n_split > 1 && (!workspace || workspace_bytes < (size_t) (n_split * N * n_head * nb3 * (DV + 2) * 4))) n_split = 1;
     const int64_t chunk = (n_kv + n_split - 1) / n_split;
-    const size_t lds = (size_t) (chunk > FA_THREADS ? chunk : FA_THREADS) * 4;
+    const size_t lds = (size_t) (chunk > FA_THREADS ? chunk : FA_THREADS) * 4 + (seq ? (size_t) n_kv * 4 : 0);
     static bool attr_set[64] = {};
     if (lds > 48 * 1024) {
         int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
@@ -1048,7 +1116,7 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
     }
     hipLaunchKernelGGL(k_flash_attn_ext, dim3((unsigned) (N * n_split), (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
                        to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2,
-                       n_split, (float *) workspace);
+                       n_split, (float *) workspace, seq);
     if (n_split > 1)
         hipLaunchKernelGGL(k_flash_attn_combine, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(256), 0, (hipStream_t) stream,
                            (const float *) workspace, n_split, DV, N, to_d(dst));

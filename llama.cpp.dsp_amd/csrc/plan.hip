@@ -723,7 +723,7 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in,
             }
             ds = wave_sum_f64(ds);
             const float inv = (float) (1.0 / ds);
-            for (int j = lane; j < cnt; j += 64) sc[j] = __half2float(__float2half_rn(__fmul_rn(sc[j], inv)));      // (a lane re-reads only what it wrote)
+            for (int j = lane; j < cnt; j += 64) sc[j] = f16_round(__fmul_rn(sc[j], inv));      // (a lane re-reads only what it wrote)
             l0 = 1.0f;
         } else {
             float ls = 0.0f;
@@ -842,39 +842,6 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in,
 // CPU's order with the same two roundings, the rescale factors having been formed in parallel (prefix maximum) by step 3.
 template <int CTRL> __device__ __forceinline__ float dpp_keep_f(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float f16_round(float x) { return __half2float(__float2half_rn(x)); }
-
-// expf as the C library of the reference's host computes it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c): x / ln2 split into k / 32 + r, a 32-entry
-// table of 2^(i/32) and a cubic in r, everything in f64, rounded once to f32 -- so an f64 restatement gives the library's bits (the device library's
-// expf is a different algorithm, 1 ulp apart in ~10 % of the arguments: enough to flip an f16 rounding of the flash accumulator now and then).
-// The table lives in the lanes of the calling wave (lane i holds entry i % 32: `tab`), read with ds_bpermute: no memory access on the serial path.
-__device__ const unsigned long long PLAN_EXP2F_T[32] = {      // bits(2^(i/32)) - (i << 47), correctly rounded (generated with 60-digit decimal arithmetic)
-    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
-    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
-    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
-    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
-__device__ __forceinline__ float expf_libm(float x, unsigned long long tab) {      // (every lane of the wave must be active: ds_bpermute)
-    const double xd = (double) x;
-    const double z = 0x1.71547652b82fep+5 * xd;                 // 32 / ln 2
-    double kd = z + 0x1.8p+52;
-    const unsigned long long ki = (unsigned long long) __double_as_longlong(kd);
-    kd -= 0x1.8p+52;
-    const double r = z - kd;
-    const int src = 4 * (int) (ki & 31ull);
-    const unsigned lo = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (unsigned) tab), hi = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (unsigned) (tab >> 32));
-    const unsigned long long t = (((unsigned long long) hi << 32) | lo) + (ki << 47);
-    const double sd = __longlong_as_double((long long) t);
-    const double zz = 0x1.c6af84b912394p-20 * r + 0x1.ebfce50fac4f3p-13;
-    const double r2 = r * r;
-    double y = 0x1.62e42ff0c52d6p-6 * r + 1.0;
-    y = zz * r2 + y;
-    y = y * sd;
-    float res = (float) y;
-    if (x < -0x1.9fe368p6f) res = 0.0f;                         // (underflow, -inf included)
-    if (x > 0x1.62e42ep6f) res = INFINITY;
-    if (x != x) res = x;
-    return res;
 }
 
 // t[I] of ggml_vec_dot_f16's reduction tree for one K row against q (see plan_attn_lds step 2): the accumulators (j, l = I) and (j, l = I + 4), j = 0..3

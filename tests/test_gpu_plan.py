@@ -342,7 +342,10 @@ def test_attention_stage_follows_the_cpu_flash_accumulator(G, torch):
         ref_exact[h] = p_ @ V[0, g].astype(np.float64)
     top = np.abs(ref_seq).max()
     d = np.abs(got - ref_seq)
-    assert d.max() <= 2e-3 * top and (d > 1e-6 * top).mean() <= 0.02, (d.max() / top, (d > 1e-6 * top).mean())
+    # measured: every one of the 4096 elements has the oracle's (= the reference CPU backend's) bits; what is left room for is a cosf / sinf of the rope
+    # one ulp from numpy's that flips the f16 rounding of a q element
+    differ = (got.astype(np.float32).view(np.uint32) != ref_seq.astype(np.float32).view(np.uint32)).mean()
+    assert d.max() <= 2e-3 * top and differ <= 0.002, (d.max() / top, differ)
     assert np.abs(got - ref_exact).max() > 1e-4 * top                       # the F16 accumulator is visible
     got0 = res["0"][0]
     assert np.abs(got0 - ref_exact).max() <= 2e-5 * top                     # the f32 accumulator: the exact product

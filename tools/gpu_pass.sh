@@ -1,6 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-export GGML_BACKEND_PATH=$PWD/llama.cpp.dsp_amd/lib/libggml-mi355.so MI355_GRAPH_STATS=1
-MP_DEBUG=1 timeout -k 10 300 oracle/_ref/avx2/model_parity --preset small --layers 4 --vocab 8192 --tokens 4 --teacher 4 --fa > gpurun_out/teacher_fa.log 2>&1; echo rc=$?
-grep -E "dbg|teacher-forced" gpurun_out/teacher_fa.log | cut -c1-220 | head -60
+timeout -k 10 200 python tools/fa_op_debug.py flash_attn_batch3_d64_kv40 2>&1 | grep -v amdgpu.ids | head -1
+timeout -k 10 200 python tools/fa_op_debug.py flash_attn_decode_gqa_d128_kv256 2>&1 | grep -v amdgpu.ids | head -1
+timeout -k 10 200 python tools/fa_exact_check.py 256 201 2>&1 | tail -2
+timeout -k 10 200 python tools/fa_exact_check.py 64 40 2>&1 | tail -2
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1; rc=$?
+tail -3 gpurun_out/gpu_tests_full.log | cut -c1-300
+[ $rc -ne 0 ] && tail -40 gpurun_out/gpu_tests_full.log | cut -c1-300
+exit $rc

@@ -68,6 +68,23 @@ if [ -x $MP ] && [ -x $MPS ]; then
   cut -c1-300 profiles/${TAG}_plugin_whole_model.md
   grep -q "exit [1-9]" profiles/${TAG}_plugin_whole_model.md && { echo "a whole-model run failed"; exit 1; }
 fi
+step "plan timeline (diagnostic build), 2 layers and 32 layers"
+if [ -f llama.cpp.dsp_amd/lib/libmi355q_dbg.so ]; then
+  {
+    echo "# $TAG: in-kernel timeline of the decode plan (libmi355q_dbg.so, tools/planstamps.py; Llama-3-8B Q4_K_M, position 100, n_kv 128)"
+    echo; echo "Stages per layer: q|k (norm), v, ATTN, wo, gate|up (norm, SiLU x up), down.  Stamps: see tools/planstamps.py."
+    echo; echo '```'
+    MI355Q_LIB=$PWD/llama.cpp.dsp_amd/lib/libmi355q_dbg.so timeout -k 10 200 python tools/planstamps.py --layers 2 2>&1 | grep -v "Warn\|amdgpu.ids\|line.append" | cut -c1-330
+    echo '```'
+    echo; echo "Whole token (32 layers + output), per-launch time with HIP events (product library):"
+    echo; echo '```'
+    timeout -k 10 200 python tools/loaderonly.py 2>&1 | tail -1
+    timeout -k 10 200 python tools/loaderonly.py --pos 250 --n-ctx 256 2>&1 | tail -1
+    MI355Q_PLAN_KV_LDS=0 timeout -k 10 200 python tools/loaderonly.py 2>&1 | tail -1 | sed 's/^/round-2 attention stage (MI355Q_PLAN_KV_LDS=0): /'
+    echo '```'
+  } > profiles/${TAG}_plan_timeline.md
+  tail -8 profiles/${TAG}_plan_timeline.md | cut -c1-200
+fi
 step "prefill shapes"
 timeout -k 10 300 python tools/ppbench.py > gpurun_out/ppbench.log 2>&1; rc=$?; tail -9 gpurun_out/ppbench.log; [ $rc -ne 0 ] && exit $rc
 cp gpurun_out/ppbench.log profiles/${TAG}_ppbench.txt
