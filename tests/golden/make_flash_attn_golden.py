@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Generate tests/golden/flash_attn_*.npz from the REAL reference: GGML_OP_FLASH_ATTN_EXT with an F16 K / V cache computed by the reference CPU
-backend (ggml-cpu/ops.cpp:6686-6905) through oracle/_ref/avx2 (refshim ref_flash_attn_ext).  The scalar build gives the same bits on these inputs
-(tests/test_oracle_glue.py checks the restatement against both).  Run where /root/reference exists:  python tests/golden/make_flash_attn_golden.py
+backend (ggml-cpu/ops.cpp:6686-6905) through oracle/_ref/avx2 (refshim ref_flash_attn_ext).  (tests/test_oracle_glue.py checks the restatement against both builds; the scalar one differs in the last place.)  Run where /root/reference exists:  python tests/golden/make_flash_attn_golden.py
 Inputs are seeded gaussians; arrays only (loadable with allow_pickle=False)."""
 import sys
 from pathlib import Path

@@ -76,26 +76,50 @@ def test_mul_mat_f_close(ref):
         assert np.abs(o - r).max() <= 2e-5 * np.abs(r).max(), code
 
 
+_FLASH_PIN_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+from oracle import glue
+variant, cfg = sys.argv[2], json.loads(sys.argv[3])
+r = oracle.Reference(variant)
+H, Hk, N, DK, n_kv, max_bias, softcap = cfg
+rng = np.random.default_rng(H * 1000 + DK + n_kv)
+q = rng.standard_normal((1, H, N, DK)).astype(np.float32)
+k = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float16); v = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float16)
+mask = np.zeros((64, n_kv), np.float16)                          # (ggml pads the mask rows to GGML_KQ_MASK_PAD)
+for t in range(N):
+    mask[t, n_kv - N + t + 1 - 3:] = -np.inf                     # causal, and the last three positions never written
+mask[:, 5] = -np.inf                                             # a hole in the middle: skipped, not weighted by zero
+if max_bias > 0:
+    mask[:N] += (rng.standard_normal((N, n_kv)) * 0.1).astype(np.float16)
+got = glue.flash_attn_ext(q, k, v, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
+want = r.flash_attn_ext(q, k, v, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
+d = np.abs(got.astype(np.float64) - want); top = float(np.abs(want).max())
+print(json.dumps({"differ": float((got.view(np.uint32) != want.view(np.uint32)).mean()), "max_rel": float(d.max() / top), "flips": float((d > 1e-6 * top).mean())}))
+"""
+
+
 @pytest.mark.parametrize("variant", ["avx2", "scalar"])
 @pytest.mark.parametrize("cfg", [(8, 2, 1, 128, 96, 0.0, 0.0), (4, 4, 3, 64, 40, 0.0, 0.0), (8, 2, 2, 128, 256, 4.0, 0.0), (4, 1, 1, 96, 64, 0.0, 10.0), (2, 2, 1, 256, 33, 0.0, 0.0)], ids=str)
 def test_flash_attn_ext_bitexact(variant, cfg):
-    """FLASH_ATTN_EXT with an F16 cache: the restatement (positions in order, running maximum, F16 accumulator, ggml_vec_dot_f16's SIMD order)
-    against the real reference CPU backend, both builds, bit for bit: decode and small prefill batches, GQA, ALiBi, soft-capping, ragged n_kv."""
+    """FLASH_ATTN_EXT with an F16 cache: the restatement (positions in order, running maximum, F16 accumulator, ggml_vec_dot_f16's SIMD order,
+    the C library's expf) against the real reference CPU backend: decode and small prefill batches, GQA, ALiBi, soft-capping, ragged n_kv.
+    BIT FOR BIT against the AVX2 build -- the one llama-bench and model_parity run; the scalar build sums the dot products in f64 and S without fma:
+    its outputs sit in the neighbouring f32 and, once in a few hundred elements, on the other side of an f16 rounding of the accumulator.
+    Each variant runs in a process of its own: the two builds export the same sonames, and a process that has loaded one resolves the other's to it."""
+    import json, subprocess, sys
+    from pathlib import Path
     if not oracle.ref_available(variant):
         pytest.skip(f"oracle/_ref/{variant} not built")
-    r = oracle.Reference(variant)
-    if not hasattr(r.lib, "ref_flash_attn_ext"):
+    root = str(Path(__file__).resolve().parents[1])
+    pr = subprocess.run([sys.executable, "-c", _FLASH_PIN_SCRIPT, root, variant, json.dumps(list(cfg))], capture_output=True, text=True, timeout=300)
+    if "ref_flash_attn_ext" in pr.stderr and "AttributeError" in pr.stderr:
         pytest.skip("refshim without ref_flash_attn_ext (stale oracle/_ref)")
-    H, Hk, N, DK, n_kv, max_bias, softcap = cfg
-    rng = np.random.default_rng(H * 1000 + DK + n_kv)
-    q = rng.standard_normal((1, H, N, DK)).astype(np.float32)
-    k = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float16); v = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float16)
-    mask = np.zeros((64, n_kv), np.float16)                          # (ggml pads the mask rows to GGML_KQ_MASK_PAD)
-    for t in range(N):
-        mask[t, n_kv - N + t + 1 - 3:] = -np.inf                     # causal, and the last three positions never written
-    mask[:, 5] = -np.inf                                             # a hole in the middle: skipped, not weighted by zero
-    if max_bias > 0:
-        mask[:N] += (rng.standard_normal((N, n_kv)) * 0.1).astype(np.float16)
-    got = glue.flash_attn_ext(q, k, v, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
-    want = r.flash_attn_ext(q, k, v, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
-    assert np.array_equal(bits(got), bits(want)), (np.abs(got - want).max(), (bits(got) != bits(want)).mean())
+    assert pr.returncode == 0, pr.stderr[-1500:]
+    st = json.loads(pr.stdout.strip().splitlines()[-1])
+    if variant == "avx2":
+        assert st["differ"] == 0.0, st
+    else:
+        assert st["max_rel"] <= 2e-3 and st["flips"] <= 0.02, st

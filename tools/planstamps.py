@@ -14,7 +14,7 @@ from ggml_mi355 import workloads as wl
 import bench as B
 
 ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, default=2); ap.add_argument("--pos", type=int, default=100)
-ap.add_argument("--n-ctx", type=int, default=128)
+ap.add_argument("--n-ctx", type=int, default=128); ap.add_argument("--csv", default=None, help="write the per-stage medians of every stamp (wave 0; us) to this file")
 a = ap.parse_args()
 ring = os.environ.get("MI355Q_PLAN_ENGINE") == "ring"
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
@@ -51,6 +51,15 @@ for st in range(n):
             continue
         line.append(f"[{i}] {np.nanmin(c0):7.2f}/{np.nanmedian(c0):7.2f}/{np.nanmax(c0):7.2f} | {np.nanmedian(c1):7.2f}")
     print("  ".join(line))
+if a.csv:
+    with open(a.csv, "w") as f:
+        f.write("stage," + ",".join(f"s{i}_min,s{i}_med,s{i}_max" for i in range(8)) + "\n")
+        for st in range(n):
+            row = []
+            for i in range(8):
+                c0 = s[st, :, 0, i]
+                row += ["", "", ""] if np.all(np.isnan(c0)) else [f"{np.nanmin(c0):.2f}", f"{np.nanmedian(c0):.2f}", f"{np.nanmax(c0):.2f}"]
+            f.write(f"{st}," + ",".join(row) + "\n")
 if not ring:
     # the attention stages, workgroup 0: every stamp of wave 0 and of wave 15 (0 entry, 1 q/k/v gathered, 2 roped + stored, 6 scores loop left, 3 scores (barrier), 4 softmax, 7 P.V loop left, 5 published)
     for st in range(n):
