@@ -74,6 +74,7 @@ struct alignas(64) PlanStage {
     int             total_rows, rows_per_wg, k, n_mats;
     // -- the rest --
     int             type, flags, prime, kind;
+    int             wg_base, wg_count, group, pub_wg;     // pub_wg: the workgroup of the range that publishes the stage's residual sum / x_out. the workgroups [wg_base, wg_base + wg_count) run this stage; group > 1: this and the next group - 1 descriptors run CONCURRENTLY on disjoint workgroups
     VecSrc          x0, x1;
     const float *   norm_w;
     Granule *       sum_gran; float * sum_plain; float * x_out;
@@ -313,7 +314,7 @@ template <typename P> __device__ __forceinline__ P uniform_ptr(P p) {
 struct StageCtx {
     uint8_t * lds; float * stg; int * ctl; double * part; unsigned * sync; unsigned long long timeout;
     unsigned grid, epoch; int even, stage, image;     // image: bytes of the activation image at the start of the LDS allocation
-    const uint8_t * next_desc, * next_attn; unsigned pre_lds;   // the next stage's descriptors (global) and a 1-KiB LDS scratch area their lines are DMA-ed into
+    const uint8_t * next_desc, * next_attn, * next_desc2; unsigned pre_lds;   // the next stage's descriptors (global; next_desc2: the one behind it -- the second member when the next stage heads a group) and a 1-KiB LDS scratch area their lines are DMA-ed into
 };
 
 // Warm this XCD's L2 with the NEXT stage's descriptor while the current stage runs: descriptors are cold after every launch boundary and a
@@ -322,9 +323,10 @@ struct StageCtx {
 __device__ __forceinline__ void plan_prefetch_desc(const StageCtx & c, int wave, int lane) {
     static_assert(sizeof(PlanStage) <= 32 * 16 && sizeof(AttnStage) <= 32 * 16, "descriptor prefetch covers 512 bytes each");
     if (wave == GEMV_WAVES - 1 && c.next_desc != nullptr) {
-        const bool second = lane >= 32;                        // lanes 0..31: the stage descriptor; lanes 32..63: its attention descriptor, if any
-        const uint8_t * base = second ? c.next_attn : c.next_desc;
-        const int n16 = second ? (int) ((sizeof(AttnStage) + 15) / 16) : (int) ((sizeof(PlanStage) + 15) / 16);
+        const bool second = lane >= 32;                        // lanes 0..31: the stage descriptor; lanes 32..63: its attention descriptor, if any, else the descriptor behind it
+        const bool attn2 = c.next_attn != nullptr;
+        const uint8_t * base = second ? (attn2 ? c.next_attn : c.next_desc2) : c.next_desc;
+        const int n16 = second && attn2 ? (int) ((sizeof(AttnStage) + 15) / 16) : (int) ((sizeof(PlanStage) + 15) / 16);
         if (base != nullptr && (lane & 31) < n16) {
             const uint8_t * g = base + 16 * (lane & 31);
             const unsigned dst = (unsigned) __builtin_amdgcn_readfirstlane((int) c.pre_lds);     // (wave-uniform by construction; the asm needs an SGPR)
@@ -345,7 +347,7 @@ __device__ __forceinline__ bool plan_gather(StageC st, const StageCtx & c, int k
     v1.plain = st->x1.plain; v1.gran = st->x1.gran; v1.tag_off = st->x1.tag_off; v1.pad = 0;
     const SrcView s0 = src_view(v0, 0, k, c.epoch);
     const SrcView s1 = src_view(two ? v1 : v0, 0, k, c.epoch);
-    const bool pub = (st->flags & PLAN_F_SUM) && blockIdx.x == (unsigned) c.stage % c.grid;
+    const bool pub = (st->flags & PLAN_F_SUM) && (int) blockIdx.x == st->pub_wg;
     const unsigned tag = c.epoch + st->tag_off;
     const int chunks = (k + 127) >> 7;
     PollCtx pc; pc.sync = c.sync; pc.timeout = c.timeout; pc.t0 = __builtin_amdgcn_s_memrealtime();
@@ -456,7 +458,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     PLAN_STAMP(0);
     const int k = st->k, flags = st->flags;
-    int r_lo = (int) blockIdx.x * st->rows_per_wg, r_hi = r_lo + st->rows_per_wg;
+    int r_lo = ((int) blockIdx.x - st->wg_base) * st->rows_per_wg, r_hi = r_lo + st->rows_per_wg;
     if (r_hi > st->total_rows) r_hi = st->total_rows;
     StageW sw;
     int pair_p0 = 0, pair_np = 0;
@@ -516,7 +518,7 @@ static __device__ __forceinline__ bool plan_stage(StageC st, const StageCtx & c)
         }
         const int spans = (k + 255) >> 8;
         float * x_out = st->x_out;
-        const bool pub_x = x_out != nullptr && blockIdx.x == (unsigned) c.stage % c.grid;
+        const bool pub_x = x_out != nullptr && (int) blockIdx.x == st->pub_wg;
 #pragma unroll 1
         for (int span = wave; span < spans; span += GEMV_WAVES) {
             const int e = span * 256 + 4 * lane;
@@ -563,7 +565,7 @@ static __device__ __noinline__ bool plan_attn(AttnC a_in, const StageCtx & c_in,
     c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
     c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
     c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
-    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.pre_lds = c_in.pre_lds;
+    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.next_desc2 = uniform_ptr(c_in.next_desc2); c.pre_lds = c_in.pre_lds;
     const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -875,7 +877,7 @@ static __device__ __noinline__ bool plan_attn_lds(AttnC a_in, const StageCtx & c
     c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
     c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
     c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
-    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.pre_lds = c_in.pre_lds;
+    c.next_desc = uniform_ptr(c_in.next_desc); c.next_attn = uniform_ptr(c_in.next_attn); c.next_desc2 = uniform_ptr(c_in.next_desc2); c.pre_lds = c_in.pre_lds;
     const unsigned tag = (unsigned) __builtin_amdgcn_readfirstlane((int) tag_in);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -1259,7 +1261,7 @@ static __device__ __noinline__ bool plan_attn_combine(AttnC a_in, const StageCtx
     c.sync = uniform_ptr(c_in.sync); c.timeout = c_in.timeout;
     c.grid = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.grid); c.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) c_in.epoch);
     c.even = c_in.even; c.stage = __builtin_amdgcn_readfirstlane(c_in.stage);
-    c.next_desc = nullptr; c.next_attn = nullptr; c.pre_lds = c_in.pre_lds;
+    c.next_desc = nullptr; c.next_attn = nullptr; c.next_desc2 = nullptr; c.pre_lds = c_in.pre_lds;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int tid = (int) threadIdx.x;
@@ -1327,8 +1329,19 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
 #pragma unroll 1
     for (int s = 0; s < n_stages; ++s) {
         StageC st = stages + s;
-        c.stage = s;
+        // A GROUP: sub-stages of one activation vector whose matrices have different weight types (wq | wk in Q4_K, wv in Q6_K) run concurrently, each on
+        // its own share of the workgroups (by weight bytes), instead of one after the other on all of them: the second used to cost a whole stage chain
+        // (descriptor, prime, memory latency: 4.6 us) for 3.4 MB.  Every member forms the activation image itself.
+        const int grp = st->group;
+        if (grp > 1) {
+            int m = 0;
+            for (int i = 1; i < grp; ++i) if ((int) blockIdx.x >= (stages + s + i)->wg_base) m = i;      // (wg_base ascending over the members)
+            st = stages + s + m;
+        }
+        c.stage = (int) (st - stages);
+        s += grp > 1 ? grp - 1 : 0;
         c.next_desc = s + 1 < n_stages ? (const uint8_t *) (stages_g + s + 1) : nullptr;
+        c.next_desc2 = s + 2 < n_stages ? (const uint8_t *) (stages_g + s + 2) : nullptr;
         c.next_attn = (const uint8_t *) st->next_attn;
         bool ok = true;
         const int kind = st->kind;
@@ -1513,6 +1526,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             if (gemv_fast_family(in.mats[i].type) != gemv_fast_family(in.mats[0].type)) { mi355q_set_error("plan_create: the matrices of a stage must share the activation format (Q8_K or Q8_0 family)"); return MI355Q_ERR_UNSUPPORTED; }
         bool done[GEMV_MAX_MATS] = { false, false, false, false };
         bool first = true;
+        const size_t first_sub = v.size();
         for (int i = 0; i < in.n_mats; ++i) {
             if (done[i]) continue;
             const int type = in.mats[i].type;
@@ -1558,6 +1572,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
             int64_t rpw = (rows + n_cu - 1) / n_cu; if (rpw < 1) rpw = 1;
             p.rows_per_wg = (int) rpw;
+            p.wg_base = 0; p.wg_count = n_cu; p.group = 1; p.pub_wg = (int) (v.size() % (size_t) n_cu);
             p.prime = plan_depth(type);
             v.push_back(p); attn_of.push_back(-1);
             set |= tbit(type);
@@ -1565,6 +1580,27 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             if (colb > lds_max) lds_max = colb;
             if ((size_t) in.k * 4 + 64 > stg_max) stg_max = (size_t) in.k * 4 + 64;
             first = false;
+        }
+        {   // sub-stages of different weight types -> one GROUP on disjoint workgroup ranges, sized by weight bytes (MI355Q_PLAN_GROUPS=0: one after the other)
+            static const bool no_groups = getenv("MI355Q_PLAN_GROUPS") && atoi(getenv("MI355Q_PLAN_GROUPS")) == 0;
+            const size_t n_sub = v.size() - first_sub;
+            if (n_sub > 1 && !no_groups && (int) n_sub <= n_cu) {
+                double tot = 0; std::vector<double> wb(n_sub);
+                for (size_t m = 0; m < n_sub; ++m) { wb[m] = (double) v[first_sub + m].total_rows * (double) mi355q_row_size(v[first_sub + m].type, in.k); tot += wb[m]; }
+                int base = 0;
+                for (size_t m = 0; m < n_sub; ++m) {
+                    PlanStage & q = v[first_sub + m];
+                    int cnt = m + 1 == n_sub ? n_cu - base : (int) (n_cu * wb[m] / tot + 0.5);
+                    const int left = (int) (n_sub - m - 1);
+                    if (cnt < 1) cnt = 1;
+                    if (cnt > n_cu - base - left) cnt = n_cu - base - left;
+                    q.wg_base = base; q.wg_count = cnt; q.group = m == 0 ? (int) n_sub : 1;
+                    q.rows_per_wg = (q.total_rows + cnt - 1) / cnt; if (q.rows_per_wg < 1) q.rows_per_wg = 1;
+                    q.flags |= PLAN_F_NEW_X | (v[first_sub].flags & PLAN_F_DIRECT);
+                    q.pub_wg = base + (int) ((first_sub + m) % (size_t) cnt);
+                    base += cnt;
+                }
+            }
         }
     }
     if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
@@ -1618,7 +1654,10 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             fixs(p.x0); fixs(p.x1); p.sum_gran = (Granule *) fix(p.sum_gran);
             p.yg = (Granule *) fix(p.yg);
             p.attn = attn_of[i] >= 0 ? pl->d_attn + attn_of[i] : nullptr;
-            p.next_attn = i + 1 < v.size() && attn_of[i + 1] >= 0 ? pl->d_attn + attn_of[i + 1] : nullptr;
+            size_t nx = i + 1;                                  // (for the members of a group: the stage behind the group)
+            if (v[i].kind == PLAN_K_GEMV && v[i].group == 1 && v[i].wg_count < n_cu) while (nx < v.size() && v[nx].kind == PLAN_K_GEMV && v[nx].group == 1 && v[nx].wg_count < n_cu && v[nx].wg_base > v[i].wg_base) ++nx;
+            if (v[i].kind == PLAN_K_GEMV && v[i].group > 1) nx = i + (size_t) v[i].group;
+            p.next_attn = nx < v.size() && attn_of[nx] >= 0 ? pl->d_attn + attn_of[nx] : nullptr;
         }
         ok = hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) == hipSuccess &&
              (va.empty() || hipMemcpy(pl->d_attn, va.data(), va.size() * sizeof(AttnStage), hipMemcpyHostToDevice) == hipSuccess) &&

@@ -352,6 +352,39 @@ def test_attention_stage_follows_the_cpu_flash_accumulator(G, torch):
     assert np.array_equal(res["0"][1].view(np.uint16), kc_a.view(np.uint16)) and np.array_equal(res["0"][2].view(np.uint16), vc_a.view(np.uint16))
 
 
+@pytest.mark.parametrize("groups", ["1", "0"], ids=["concurrent", "one_after_the_other"])
+def test_mixed_type_stage_runs_as_a_group(G, torch, groups):
+    """One activation vector, matrices of three weight types of one activation format (Q4_K, Q6_K, Q5_K), a norm prologue with the residual sum and x_out:
+    the sub-stages run CONCURRENTLY on disjoint workgroup ranges (MI355Q_PLAN_GROUPS=0: one after the other, round 2's form).  Every output, the
+    published sum and the stored vector are bit-identical to the node ops either way, and a following stage sees all three outputs."""
+    import os
+    rng = np.random.default_rng(91)
+    K = 4096
+    wa, wb, wc = W(G, oracle.Q4_K, 5120, K, rng), W(G, oracle.Q6_K, 1024, K, rng), W(G, oracle.Q5_K, 300, K, rng)
+    x0 = dev(torch, rng.standard_normal((1, K)).astype(np.float32)); x1 = dev(torch, rng.standard_normal((1, K)).astype(np.float32))
+    nw = dev(torch, (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    z = lambda n: torch.zeros((1, n), dtype=torch.float32, device="cuda")
+    ya, yb, yc, so, xo, y2 = z(5120), z(1024), z(300), z(K), z(K), z(64)
+    w2 = W(G, oracle.Q4_K, 64, 1024, rng)
+    os.environ["MI355Q_PLAN_GROUPS"] = groups
+    try:
+        plan = G.Plan([dict(ws=[wa, wb, wc], ys=[ya, yb, yc], x=x0, x1=x1, x_kind=G.X_NORM, norm_w=nw, eps=1e-5, sum_out=so, x_out=xo),
+                       dict(ws=[w2], ys=[y2], x=yb)])
+    finally:
+        del os.environ["MI355Q_PLAN_GROUPS"]
+    r_x, r_sum = G.op_add_rms_norm_mul(x0, 1e-5, b=x1, weight=nw, want_sum=True)
+    for rep in range(2):
+        for b in (ya, yb, yc, so, xo, y2):
+            b.zero_()
+        plan.run(); torch.cuda.synchronize()
+        assert plan.status() == 0
+        assert np.array_equal(bits(xo), bits(r_x)) and np.array_equal(bits(so), bits(r_sum))
+        for y, w in ((ya, wa), (yb, wb), (yc, wc)):
+            assert np.array_equal(bits(y), bits(G.mul_mat(w, r_x)))
+        assert np.array_equal(bits(y2), bits(G.mul_mat(w2, G.mul_mat(wb, r_x))))
+    plan.close()
+
+
 def test_plan_timeout_is_reported_not_hung(G, torch):
     """An operand that claims to come from an earlier stage but is never produced cannot be built through the API (dependencies follow
     from addresses), so the bounded poll is exercised the only way possible: a plan whose launch is healthy reports status 0 repeatedly,
