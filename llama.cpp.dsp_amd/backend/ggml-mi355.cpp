@@ -113,9 +113,15 @@ static bool mi355_is_quant(enum ggml_type t) { return mi355q_type_supported((int
 // the tensor whose shape defines the device row layout (views share their source's rows)
 static const struct ggml_tensor * mi355_root(const struct ggml_tensor * t) { return t->view_src ? t->view_src : t; }
 
-// rows of a quantized tensor are stored planar iff (type, ne0) says so -- same predicate everywhere
+// A Q8_0 tensor outside a weight buffer is (or may become) a KV cache (-ctk q8_0 / -ctv q8_0): the device writes its rows block by block (CPY) and the
+// attention kernel reads heads out of them, so it keeps the CANONICAL block order; only Q8_0 tensors in buffers the application marked as weights are planar.
+static bool mi355_q80_canonical(const struct ggml_tensor * t) {
+    const struct ggml_tensor * r = mi355_root(t);
+    return t->type == GGML_TYPE_Q8_0 && !(r->buffer && r->buffer->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+}
+// rows of a quantized tensor are stored planar iff (type, ne0, and for Q8_0 the buffer's usage) say so -- same predicate everywhere
 static bool mi355_rows_planar(const struct ggml_tensor * t) {
-    return mi355_is_quant(t->type) && mi355q_weights_are_planar((int) t->type, mi355_root(t)->ne[0]) == 1;
+    return mi355_is_quant(t->type) && mi355q_weights_are_planar((int) t->type, mi355_root(t)->ne[0]) == 1 && !mi355_q80_canonical(t);
 }
 
 // ------------------------------------------------------------------------------------------------ buffer
@@ -265,10 +271,22 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, struct ggml_tensor * dst, con
     const int64_t K = src0->ne[0], M = src0->ne[1], N = src1->ne[1];
     const int64_t r2 = src1->ne[2] / src0->ne[2], r3 = src1->ne[3] / src0->ne[3];
     const size_t  ws = mi355q_mul_mat_workspace((int) src0->type, M, N, K);
-    void * wsp = ws ? mi355_workspace(ctx, ws) : nullptr;
+    // (a Q8_0 matrix that is not in a weight buffer holds canonical rows: the library's kernels read device rows, so a slice is packed into scratch first --
+    //  the reference harness' MUL_MAT cases and a quantized K cache read by a plain MUL_MAT come this way, model weights never do)
+    // The whole ROOT tensor is packed (its rows are dense; a permuted view's are not) and the view's addresses are carried over: the device layout
+    // permutes bytes inside a row only.
+    const struct ggml_tensor * root = mi355_root(src0);
+    const bool   pack = mi355_q80_canonical(src0) && mi355q_weights_are_planar((int) src0->type, K) == 1 && root->ne[0] == K && ggml_is_contiguous(root);
+    const size_t wsa = (ws + 255) & ~(size_t) 255, pk = pack ? ggml_nbytes(root) : 0;
+    void * wsp = (ws || pk) ? mi355_workspace(ctx, wsa + pk) : nullptr;
+    const char * w_base = (const char *) src0->data;
+    if (pack) {
+        MQ_CHECK(mi355q_weights_pack_d2d((int) src0->type, (char *) wsp + wsa, root->data, ggml_nelements(root) / K, K, ctx->stream));
+        w_base = (const char *) wsp + wsa + ((const char *) src0->data - (const char *) root->data);
+    }
     for (int64_t i13 = 0; i13 < src1->ne[3]; ++i13) {
         for (int64_t i12 = 0; i12 < src1->ne[2]; ++i12) {
-            const char * w = (const char *) src0->data + (i12 / r2) * src0->nb[2] + (i13 / r3) * src0->nb[3];
+            const char * w = w_base + (i12 / r2) * src0->nb[2] + (i13 / r3) * src0->nb[3];
             const char * x = (const char *) (x_alias ? x_alias : src1->data) + i12 * src1->nb[2] + i13 * src1->nb[3];
             char *       y = (char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3];
             MQ_CHECK(mi355q_mul_mat((int) src0->type, w, (int64_t) src0->nb[1], (const float *) x, (int64_t) src1->nb[1],
@@ -286,8 +304,12 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, struct ggml_tensor * dst) 
     const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
     const int64_t n_used = ids->ne[0], n_tok = ids->ne[1], b_ne1 = b->ne[1];
     const size_t  ws = mi355q_mul_mat_id_workspace((int) as->type, M, K, n_used, n_tok, b_ne1, n_expert);
-    void * wsp = ws ? mi355_workspace(ctx, ws) : nullptr;
-    MQ_CHECK(mi355q_mul_mat_id((int) as->type, as->data, (int64_t) as->nb[1], (int64_t) as->nb[2], n_expert,
+    const bool   pack = mi355_q80_canonical(as) && mi355q_weights_are_planar((int) as->type, K) == 1 && as->nb[2] == as->nb[1] * (size_t) M;     // (see mi355_mul_mat)
+    const size_t wsa = (ws + 255) & ~(size_t) 255, pk = pack ? (size_t) n_expert * (size_t) as->nb[2] : 0;
+    void * wsp = (ws || pk) ? mi355_workspace(ctx, wsa + pk) : nullptr;
+    const void * as_data = as->data;
+    if (pack) { MQ_CHECK(mi355q_weights_pack_d2d((int) as->type, (char *) wsp + wsa, as->data, M * n_expert, K, ctx->stream)); as_data = (const char *) wsp + wsa; }
+    MQ_CHECK(mi355q_mul_mat_id((int) as->type, as_data, (int64_t) as->nb[1], (int64_t) as->nb[2], n_expert,
                                (const float *) b->data, b_ne1, (int64_t) b->nb[1], (int64_t) b->nb[2],
                                (const int32_t *) ids->data, (int64_t) ids->nb[1],
                                (float *) dst->data, M, K, n_used, n_tok, wsp, ws, 0, ctx->stream));
@@ -350,7 +372,7 @@ static void mi355_backend_synchronize(ggml_backend_t backend) {
 // ---- residency ops: thin wrappers over mi355q_op_* -- the tensor descriptor is ggml's ne[] / nb[] verbatim
 static mi355q_tensor mi355_td(const struct ggml_tensor * t) {
     mi355q_tensor d;
-    d.data = t->data; d.type = t->type == GGML_TYPE_F16 ? MI355Q_T_F16 : MI355Q_T_F32;
+    d.data = t->data; d.type = t->type == GGML_TYPE_F16 ? MI355Q_T_F16 : t->type == GGML_TYPE_Q8_0 ? MI355Q_TYPE_Q8_0 : MI355Q_T_F32;     // (Q8_0: a quantized KV cache, CPY destination / FLASH_ATTN_EXT operand)
     for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t) t->nb[i]; }
     return d;
 }
@@ -550,7 +572,7 @@ static bool mi355_joinable_mat(const struct ggml_tensor * n) {
     if (n->op != GGML_OP_MUL_MAT || !mi355_is_quant(n->src[0]->type)) return false;
     const struct ggml_tensor * w = n->src[0], * x = n->src[1];
     return x->type == GGML_TYPE_F32 && x->ne[2] == 1 && x->ne[3] == 1 && w->ne[2] == 1 && w->ne[3] == 1 &&
-           mi355q_weights_are_planar((int) w->type, w->ne[0]) == 1;
+           mi355q_weights_are_planar((int) w->type, w->ne[0]) == 1 && !mi355_q80_canonical(w);
 }
 
 static bool mi355_operand_ok(const struct ggml_tensor * t);
@@ -960,6 +982,7 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
         if (a->nb[0] != ggml_type_size(a->type) || mi355_root(a)->ne[0] != a->ne[0]) return false;
         if (a->nb[1] < ggml_row_size(a->type, a->ne[0])) return false;
         if (mi355q_weights_are_planar((int) a->type, a->ne[0]) && (a->nb[1] % 16 || a->nb[2] % 16 || a->nb[3] % 16)) return false;
+        if (mi355_q80_canonical(a) && mi355q_weights_are_planar((int) a->type, a->ne[0]) && !ggml_is_contiguous(mi355_root(a))) return false;   // (packed as a whole before the product: mi355_mul_mat)
         // src1 / dst: rows contiguous (any row pitch); permuted activations stay on the CPU
         if (b->nb[0] != sizeof(float) || b->nb[1] < b->ne[0] * sizeof(float)) return false;
         if (op->nb[0] != sizeof(float) || !ggml_is_contiguous(op)) return false;
@@ -995,6 +1018,9 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
     }
     case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
         const struct ggml_tensor * a = op->src[0];
+        if (op->op == GGML_OP_CPY && op->type == GGML_TYPE_Q8_0)      // the K / V stores of a quantized cache (-ctk q8_0 -ctv q8_0): whole blocks, contiguous destination
+            return a->type == GGML_TYPE_F32 && mi355_operand_ok(a) && a->nb[0] == sizeof(float) && a->ne[0] % 32 == 0 && op->ne[0] % 32 == 0 &&
+                   ggml_is_contiguous(op) && ggml_nelements(a) == ggml_nelements(op) && mi355_q80_canonical(op);
         return mi355_f32_or_f16(a->type) && mi355_f32_or_f16(op->type) && mi355_operand_ok(a) && ggml_nelements(a) == ggml_nelements(op);
     }
     case GGML_OP_GET_ROWS: {
@@ -1022,11 +1048,13 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
         if (op->src[2] && op->src[2]->type != GGML_TYPE_F32) return false;
         return a->ne[0] % 2 == 0;
     }
-    case GGML_OP_FLASH_ATTN_EXT: {                            // f16 KV cache, f32 queries, f16 mask; quantized caches stay on the CPU
+    case GGML_OP_FLASH_ATTN_EXT: {                            // f16 or Q8_0 KV cache, f32 queries, f16 mask; other cache types stay on the CPU
         const struct ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
-        if (q->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+        const bool kv_q80 = k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0;       // a Q8_0 cache: the one-workgroup-per-row kernel with the CPU's arithmetic
+        if (q->type != GGML_TYPE_F32 || !((k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16) || kv_q80) || op->type != GGML_TYPE_F32) return false;
         if (!mi355_operand_ok(q) || !mi355_operand_ok(k) || !mi355_operand_ok(v) || (m && !mi355_operand_ok(m))) return false;
-        if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || !ggml_is_contiguous(op)) return false;
+        if (q->nb[0] != 4 || k->nb[0] != (kv_q80 ? 34u : 2u) || v->nb[0] != (kv_q80 ? 34u : 2u) || !ggml_is_contiguous(op)) return false;
+        if (kv_q80 && (k->ne[0] % 32 || v->ne[0] % 32 || k->ne[1] > 8192 || !mi355_q80_canonical(k) || !mi355_q80_canonical(v))) return false;
         if (m && (m->type != GGML_TYPE_F16 || m->nb[0] != 2 || m->ne[0] < k->ne[1] || m->ne[1] < q->ne[1] || m->ne[2] != 1 || m->ne[3] != 1)) return false;
         return k->ne[0] <= 256 && v->ne[0] <= 256 && k->ne[1] >= 1 && k->ne[1] <= 36864 && q->ne[2] <= 65535 && q->ne[3] <= 65535;
     }

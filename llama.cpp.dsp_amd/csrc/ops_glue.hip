@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 
 #include "mi355q_common.h"
+#include "act_quant.cuh"
 
 namespace mi355q {
 
@@ -262,6 +263,30 @@ __global__ void __launch_bounds__(256) k_cpy_transpose(const TensorD a, TensorD 
 static int grid_for(int64_t n);
 static bool cpy_same_shape(const mi355q_tensor * a, const mi355q_tensor * d) { return a->ne[0] == d->ne[0] && a->ne[1] == d->ne[1] && a->ne[2] == d->ne[2] && a->ne[3] == d->ne[3]; }
 // picks the form; returns false when the generic element-wise kernel has to run
+// ---- CPY f32 -> Q8_0 (the K / V stores of a quantized cache, -ctk q8_0 / -ctv q8_0; the reference: ggml-cuda/cpy.cu:71,416-423, CPU: dup -> from_float) ----
+// The CPU quantizes source row by source row into a contiguous destination (ggml_compute_forward_dup_f32, quantized dst): logical block b of 32
+// elements -> bytes [34 b, 34 b + 34) of the destination.  Eight lanes own one block (q80_group8: quantize_row_q8_0_ref's arithmetic, round half
+// away from zero -- the CPU's SIMD quantizer rounds half to even, the same one-in-a-million tie as in the matmul path's activation quantizer).
+__global__ void __launch_bounds__(256) k_cpy_f32_q8_0(const TensorD a, char * dst, int64_t n_blocks, char * const * dest_table, int dest_index) {
+    if (dest_table) dst = dest_table[dest_index];
+    const int lane8 = threadIdx.x & 7;
+    for (int64_t b0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 3; b0 < ((n_blocks + 31) & ~(int64_t) 31); b0 += ((int64_t) gridDim.x * blockDim.x) >> 3) {
+        const int64_t b = b0 < n_blocks ? b0 : n_blocks - 1;    // (every lane of a wave takes part in the group reductions; surplus groups redo the last block)
+        const int64_t e = 32 * b + 4 * lane8;
+        const int64_t a0 = e % a.ne[0], ar = e / a.ne[0], a1 = ar % a.ne[1], ar2 = ar / a.ne[1], a2 = ar2 % a.ne[2], a3 = ar2 / a.ne[2];
+        const float * src = (const float *) (a.data + a0 * 4 + a1 * a.nb[1] + a2 * a.nb[2] + a3 * a.nb[3]);
+        const float4 v = make_float4(src[0], src[1], src[2], src[3]);
+        uint32_t q; float d; int sum;
+        q80_group8<false>(v, q, d, sum);
+        if (b0 < n_blocks) {
+            char * blk = dst + 34 * b;                           // 2-byte aligned: the quants are stored as halves of a word
+            if (lane8 == 0) *(__half *) blk = __float2half_rn(d);
+            *(uint16_t *) (blk + 2 + 4 * lane8) = (uint16_t) (q & 0xFFFFu);
+            *(uint16_t *) (blk + 4 + 4 * lane8) = (uint16_t) (q >> 16);
+        }
+    }
+}
+
 static bool cpy_fast(const mi355q_tensor * a, const mi355q_tensor * d, char * const * table, int index, hipStream_t st) {
     const int64_t n = nelements(d);
     if (n < 16384) return false;
@@ -626,6 +651,97 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
     }
 }
 
+// ---- FLASH_ATTN_EXT on a Q8_0 K / V cache (-ctk q8_0 -ctv q8_0; the reference: ggml-cuda/fattn.cu:244, CPU: ops.cpp:6686-6905) --------------
+// One workgroup per (query row, head, batch), the CPU's arithmetic: q quantized to Q8_0 (the vec_dot_type of a Q8_0 K; the SIMD quantize_row_q8_0), scores by
+// ggml_vec_dot_q8_0_q8_0 in its AVX2 order (per block d = d_k * d_q, eight f32 lane sums of four int8 products each fed by fma, hsum tree), the online
+// softmax walked in order (prefix maximum, as in k_flash_attn_ext's seq mode), V dequantized (q * d) into an F32 accumulator: scale by f32 multiply when
+// the maximum grows, v * weight by f32 fma per position (ggml_vec_scale_f32 / ggml_vec_mad_f32).
+__global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext_q80(const TensorD q, const TensorD k, const TensorD v, const TensorD m, int has_mask, const TensorD d,
+                                                                   float scale, float max_bias, float softcap, float m0, float m1, uint32_t n_head_log2) {
+    extern __shared__ __attribute__((aligned(16))) float fq_s[];             // [n_kv] scores -> weights | [n_kv] rescale factors | q: [DK / 32] block scales, [DK / 4] packed quants
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int64_t DK = k.ne[0], DV = v.ne[0], n_kv = k.ne[1];
+    const int64_t hk = h / (q.ne[2] / k.ne[2]), hv = h / (q.ne[2] / v.ne[2]), bk = b / (q.ne[3] / k.ne[3]), bv = b / (q.ne[3] / v.ne[3]);
+    float * msv = fq_s + n_kv, * qd = msv + n_kv;
+    uint32_t * qq = (uint32_t *) (qd + (DK >> 5));
+    const float slope = max_bias > 0.0f ? ((uint32_t) h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const __half * mp = has_mask ? (const __half *) (m.data + t * m.nb[1]) : nullptr;
+    // ---- q -> Q8_0 (whole waves take part: the 8-lane reductions)
+    if (tid < ((DK / 4 + 63) & ~63)) {
+        const float * qp = (const float *) (q.data + t * q.nb[1] + h * q.nb[2] + b * q.nb[3]);
+        const int e = 4 * tid;
+        const float4 x = e < DK ? make_float4(qp[e], qp[e + 1], qp[e + 2], qp[e + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t pq; float dq; int sum;
+        q80_group8<true>(x, pq, dq, sum);                                     // (round half to even: the CPU's SIMD quantize_row_q8_0, ggml-cpu-quants.c:842-845)
+        if (e < DK) { qq[tid] = pq; if ((tid & 7) == 0) qd[tid >> 3] = __half2float(__float2half_rn(dq)); }
+    }
+    __syncthreads();
+    // ---- scores: one position per thread
+    const int nblk = (int) (DK >> 5);
+    for (int64_t j = tid; j < n_kv; j += FA_THREADS) {
+        const float mv = mp ? __fmul_rn(slope, __half2float(mp[j])) : 0.0f;
+        float s = -INFINITY;
+        if (mv != -INFINITY) {                                                // (a masked position is skipped by the CPU whatever its cache row holds)
+            const char * row = k.data + j * k.nb[1] + hk * k.nb[2] + bk * k.nb[3];
+            float acc[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+            for (int blk = 0; blk < nblk; ++blk) {
+                const char * kb = row + 34 * blk;
+                const float dd = __fmul_rn(__half2float(*(const __half *) kb), qd[blk]);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const uint32_t kw = (uint32_t) *(const uint16_t *) (kb + 2 + 4 * l) | ((uint32_t) *(const uint16_t *) (kb + 4 + 4 * l) << 16);
+                    acc[l] = __builtin_fmaf(dd, (float) dot4((int) kw, (int) qq[8 * blk + l], 0), acc[l]);
+                }
+            }
+            const float t0 = __fadd_rn(acc[0], acc[4]), t1 = __fadd_rn(acc[1], acc[5]), t2 = __fadd_rn(acc[2], acc[6]), t3 = __fadd_rn(acc[3], acc[7]);
+            s = __fadd_rn(__fadd_rn(t0, t2), __fadd_rn(t1, t3));              // hsum_float_8
+            s = __fmul_rn(s, scale);
+            if (softcap != 0.0f) s = softcap * tanhf(s);
+            s = __fadd_rn(s, mv);
+        }
+        fq_s[j] = s;
+    }
+    __syncthreads();
+    // ---- online softmax in order: rescale factor and weight per position
+    if (wave == 0) {
+        const unsigned long long tab = PLAN_EXP2F_T[lane & 31];
+        float carry = -INFINITY;
+        for (int64_t j0 = 0; j0 < n_kv; j0 += 64) {
+            const int64_t j = j0 + lane;
+            const float sj = j < n_kv ? fq_s[j] : -INFINITY;
+            float x = sj;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(x, off, 64); if (lane >= off) x = fmaxf(x, o); }
+            float prev = __shfl_up(x, 1, 64);
+            prev = fmaxf(lane == 0 ? -INFINITY : prev, carry);
+            carry = fmaxf(carry, __shfl(x, 63, 64));
+            const bool live = sj != -INFINITY, newmax = live && sj > prev;
+            const float e = expf_libm(newmax ? __fsub_rn(prev, sj) : live ? __fsub_rn(sj, prev) : 0.0f, tab);
+            if (j < n_kv) { fq_s[j] = newmax ? 1.0f : live ? e : 0.0f; msv[j] = newmax ? e : 1.0f; }
+        }
+    }
+    __syncthreads();
+    // ---- V . P in an F32 accumulator, a thread per output dim
+    if (tid < DV) {
+        const char * vb = v.data + hv * v.nb[2] + bv * v.nb[3] + 34 * (tid >> 5);
+        const int e = tid & 31;
+        float acc = 0.0f, S = 0.0f;
+#pragma unroll 4
+        for (int64_t j = 0; j < n_kv; ++j) {
+            const float vs = fq_s[j], ms = msv[j];
+            if (vs != 0.0f || ms != 1.0f) {                                   // (uniform)
+                const char * blk = vb + j * v.nb[1];
+                const float vv = __fmul_rn((float) (int) *(const int8_t *) (blk + 2 + e), __half2float(*(const __half *) blk));     // dequantize_row_q8_0
+                if (ms != 1.0f) acc = __fmul_rn(acc, ms);                     // ggml_vec_scale_f32
+                acc = __builtin_fmaf(vv, vs, acc);                            // ggml_vec_mad_f32
+                S = __fadd_rn(__fmul_rn(S, ms), vs);
+            }
+        }
+        *(float *) (d.data + tid * d.nb[0] + h * d.nb[1] + t * d.nb[2] + b * d.nb[3]) = __fmul_rn(acc, __fdiv_rn(1.0f, S));
+    }
+}
+
 // merge the pieces of a split row: out = sum_s e^(m_s - M) o_s / sum_s e^(m_s - M) l_s
 __global__ void __launch_bounds__(256) k_flash_attn_combine(const float * __restrict__ part, int n_split, int64_t DV, int64_t N, const TensorD d) {
     const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -884,8 +1000,22 @@ int mi355q_op_unary_mul(int uop, const mi355q_tensor * a, const mi355q_tensor * 
     OPS_LAUNCHED();
 }
 
+// f32 -> Q8_0: contiguous destination, source rows of whole blocks with unit stride along dim 0 (what ggml_compute_forward_dup_f32 requires too)
+static int cpy_to_q8_0(const mi355q_tensor * a, const mi355q_tensor * dst, char * const * table, int index, hipStream_t st) {
+    const int64_t n = nelements(dst);
+    if (a->type != 0 || a->nb[0] != 4 || a->ne[0] % 32 != 0 || dst->ne[0] % 32 != 0 || dst->nb[0] != 34) return MI355Q_ERR_UNSUPPORTED;
+    if (dst->nb[1] != dst->ne[0] / 32 * 34 || dst->nb[2] != dst->nb[1] * dst->ne[1] || dst->nb[3] != dst->nb[2] * dst->ne[2]) return MI355Q_ERR_UNSUPPORTED;
+    if (n == 0) return MI355Q_OK;
+    hipLaunchKernelGGL(k_cpy_f32_q8_0, dim3(grid_for(n / 4)), dim3(256), 0, st, to_d(a), (char *) dst->data, n / 32, table, index);
+    return MI355Q_OK;
+}
+
 int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * stream) {
     if (!a || !dst || nelements(a) != nelements(dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_cpy: element counts differ");
+    if (dst->type == MI355Q_TYPE_Q8_0) {
+        if (cpy_to_q8_0(a, dst, nullptr, 0, (hipStream_t) stream) != MI355Q_OK) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 -> q8_0 needs a contiguous destination and source rows of whole 32-blocks");
+        OPS_LAUNCHED();
+    }
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 / f16 only");
     const int64_t n = nelements(dst);
     if (n == 0) return MI355Q_OK;
@@ -896,6 +1026,10 @@ int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * str
 
 int mi355q_op_cpy_indirect(const mi355q_tensor * a, const mi355q_tensor * dst, void * const * dest_table, int index, void * stream) {
     if (!a || !dst || !dest_table || index < 0 || nelements(a) != nelements(dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_cpy_indirect: arguments");
+    if (dst->type == MI355Q_TYPE_Q8_0) {
+        if (cpy_to_q8_0(a, dst, (char * const *) dest_table, index, (hipStream_t) stream) != MI355Q_OK) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 -> q8_0 needs a contiguous destination and source rows of whole 32-blocks");
+        OPS_LAUNCHED();
+    }
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 / f16 only");
     const int64_t n = nelements(dst);
     if (n == 0) return MI355Q_OK;
@@ -1056,12 +1190,13 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
                              const mi355q_tensor * dst, float scale, float max_bias, float logit_softcap,
                              void * workspace, size_t workspace_bytes, void * stream) {
     if (!q || !k || !v || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: null tensor");
-    if (q->type != 0 || k->type != 1 || v->type != 1 || dst->type != 0 || (mask && mask->type != 1)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q f32, k / v / mask f16, dst f32");
+    const bool kv_q80 = k->type == MI355Q_TYPE_Q8_0 && v->type == MI355Q_TYPE_Q8_0;
+    if (q->type != 0 || !((k->type == 1 && v->type == 1) || kv_q80) || dst->type != 0 || (mask && mask->type != 1)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q f32, k / v both f16 or both q8_0, mask f16, dst f32");
     const int64_t DK = k->ne[0], DV = v->ne[0], n_kv = k->ne[1], N = q->ne[1], n_head = q->ne[2], nb3 = q->ne[3];
     if (q->ne[0] != DK || v->ne[1] != n_kv || k->ne[2] <= 0 || v->ne[2] <= 0 || n_head % k->ne[2] || n_head % v->ne[2] || k->ne[3] <= 0 || v->ne[3] <= 0 ||
         nb3 % k->ne[3] || nb3 % v->ne[3] || dst->ne[0] != DV || dst->ne[1] != n_head || dst->ne[2] != N || dst->ne[3] != nb3)
         OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: q [DK, N, H, B], k [DK, n_kv, Hk, Bk], v [DV, n_kv, Hv, Bv], dst [DV, H, N, B]");
-    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: innermost dimensions must be contiguous");
+    if (q->nb[0] != 4 || k->nb[0] != (kv_q80 ? 34 : 2) || v->nb[0] != (kv_q80 ? 34 : 2) || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: innermost dimensions must be contiguous");
     if (mask && (mask->ne[0] < n_kv || mask->ne[1] < N || mask->nb[0] != 2)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: mask f16 [>= n_kv, >= N]");
     if (DK > 256 || DV > 256 || DK < 1 || DV < 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: head sizes up to 256");
     if (n_kv > 36864) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: n_kv > 36864 (one row of scores lives in LDS)");
@@ -1071,6 +1206,21 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
     if (logit_softcap != 0.0f) scale /= logit_softcap;                          // ops.cpp:6757-6759
     uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= (uint32_t) n_head) n_head_log2 *= 2;
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    if (kv_q80) {                                            // a quantized cache: one workgroup per row with the CPU's arithmetic (k_flash_attn_ext_q80)
+        if (DK % 32 || DV % 32 || n_kv > 8192) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q8_0 cache needs head sizes of whole 32-blocks and n_kv <= 8192");
+        const size_t lds = (size_t) (2 * n_kv + DK / 32 + DK / 4) * 4;
+        static bool attr_q80[64] = {};
+        if (lds > 48 * 1024) {
+            int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
+            if (!attr_q80[dev]) {
+                if (hipFuncSetAttribute((const void *) k_flash_attn_ext_q80, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "op_flash_attn_ext: LDS attribute");
+                attr_q80[dev] = true;
+            }
+        }
+        hipLaunchKernelGGL(k_flash_attn_ext_q80, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
+                           to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2);
+        OPS_LAUNCHED();
+    }
     // Many query rows (prefill) and scratch for the scores: the three steps of the definition on the matrix-core kernels -- scores = K q
     // (k_mul_mat_f16_mfma), row softmax with the f16 mask (k_soft_max), out = P V with V read transposed (k_mul_mat_f16_mfma<true>).  One
     // workgroup per row (below) re-streams K and V for every row: 5x slower for a 512-token batch.

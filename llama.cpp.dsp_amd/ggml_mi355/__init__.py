@@ -414,6 +414,21 @@ def _td(t) -> _Tensor:
     return d
 
 
+def _td_q8_0(t) -> _Tensor:
+    """uint8 torch tensor holding contiguous block_q8_0 rows, shape [..., n / 32 * 34] (<= 4 dims) -> mi355q_tensor of type Q8_0 with ne[0] = n."""
+    torch = _torch()
+    assert t.dtype == torch.uint8 and t.is_contiguous() and 1 <= t.dim() <= 4 and t.shape[-1] % 34 == 0
+    shape = list(t.shape)[::-1] + [1] * (4 - t.dim())
+    d = _Tensor(); d.data = t.data_ptr(); d.type = 8
+    d.ne[0] = shape[0] // 34 * 32; d.nb[0] = 34
+    d.nb[1] = shape[0]
+    for i in range(1, 4):
+        d.ne[i] = shape[i]
+        if i > 1:
+            d.nb[i] = d.nb[i - 1] * shape[i - 1]
+    return d
+
+
 def op_bin_bcast(op: int, a, b, out=None):
     """GGML_OP_ADD/SUB/MUL/DIV: out = a (op) b with ggml broadcasting of b over a (shapes given torch-style)."""
     torch = _torch()
@@ -463,14 +478,19 @@ def op_flash_attn_ext(q, k, v, mask, scale: float, max_bias: float = 0.0, logit_
     out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), dtype=torch.float32, device=q.device)
     ws, wsb = (_workspace(torch, int(lib().mi355q_op_flash_attn_ext_workspace(v.shape[3], q.shape[2], q.shape[1], q.shape[0], k.shape[2])), q.device)
                if split else (None, 0))
-    _check(lib().mi355q_op_flash_attn_ext(C.byref(_td(q)), C.byref(_td(k)), C.byref(_td(v)), C.byref(_td(mask)) if mask is not None else None,
+    tdkv = _td_q8_0 if k.dtype == torch.uint8 else _td                  # (uint8: block_q8_0 rows, a quantized cache)
+    if k.dtype == torch.uint8:
+        out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3] // 34 * 32), dtype=torch.float32, device=q.device)
+    _check(lib().mi355q_op_flash_attn_ext(C.byref(_td(q)), C.byref(tdkv(k)), C.byref(tdkv(v)), C.byref(_td(mask)) if mask is not None else None,
                                           C.byref(_td(out)), scale, max_bias, logit_softcap, ws.data_ptr() if ws is not None else None, wsb,
                                           _stream(torch)), "op_flash_attn_ext")
     return out
 
 
 def op_cpy(a, out):
-    _check(lib().mi355q_op_cpy(C.byref(_td(a)), C.byref(_td(out)), _stream(_torch())), "op_cpy")
+    """GGML_OP_CPY; a uint8 `out` of shape [..., n / 32 * 34] is a Q8_0 destination (quantized KV cache rows)."""
+    td_out = _td_q8_0(out) if out.dtype == _torch().uint8 else _td(out)
+    _check(lib().mi355q_op_cpy(C.byref(_td(a)), C.byref(td_out), _stream(_torch())), "op_cpy")
     return out
 
 

@@ -157,6 +157,8 @@ class Reference:
             L.ref_glue_op.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]
         if hasattr(L, "ref_flash_attn_ext"):
             L.ref_flash_attn_ext.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _i32]
+        if hasattr(L, "ref_flash_attn_ext_t"):
+            L.ref_flash_attn_ext_t.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp, _vp, _i32]
 
     def blck_size(self, t): return self.lib.ref_blck_size(t)
     def type_size(self, t): return self.lib.ref_type_size(t)
@@ -245,6 +247,20 @@ class Reference:
         if rc != 0:
             raise RuntimeError(f"ref_flash_attn_ext failed: {rc}")
         return out
+
+    def flash_attn_ext_q8_0(self, q, k, v, mask, scale: float, max_bias: float = 0.0, softcap: float = 0.0, n_threads: int = 1):
+        """FLASH_ATTN_EXT on a Q8_0 K / V cache on the reference CPU backend: k / v (f32) are quantized by the reference quantizer
+        (ggml_quantize_chunk).  Returns (out [B, N, H, DV] f32, k blocks uint8 [B, Hk, n_kv, DK/32*34], v blocks likewise)."""
+        q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+        ne = lambda x: np.asarray(list(x.shape)[::-1], np.int64)
+        m = np.ascontiguousarray(mask, np.float32) if mask is not None else None
+        out = np.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), np.float32)
+        kb = np.empty(k.shape[:-1] + (k.shape[-1] // 32 * 34,), np.uint8); vb = np.empty(v.shape[:-1] + (v.shape[-1] // 32 * 34,), np.uint8)
+        rc = self.lib.ref_flash_attn_ext_t(_ptr(q), _ptr(ne(q)), _ptr(k), _ptr(ne(k)), _ptr(v), _ptr(ne(v)), _ptr(m) if m is not None else None,
+                                           m.shape[0] if m is not None else 0, scale, max_bias, softcap, Q8_0, _ptr(out), _ptr(kb), _ptr(vb), n_threads)
+        if rc != 0:
+            raise RuntimeError(f"ref_flash_attn_ext_t failed: {rc}")
+        return out, kb, vb
 
     def bench_chain(self, types, Ms, Ks, N: int, n_threads: int, warmup: int, iters: int) -> float:
         ty = np.asarray(types, np.int32); ms = np.asarray(Ms, np.int64); ks = np.asarray(Ks, np.int64)

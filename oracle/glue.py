@@ -202,3 +202,85 @@ def flash_attn_ext(q: np.ndarray, k: np.ndarray, v: np.ndarray, mask: np.ndarray
                     S = f32(f32(S * ms) + vs)
                 out[b, n, h] = acc.astype(f32) * f32(f32(1.0) / S)
     return out
+
+
+def quantize_row_q8_0_simd(x: np.ndarray):
+    """quantize_row_q8_0 in its AVX2 form (ggml-cpu-quants.c:738-…, rounding :842-845): per 32 elements d = amax / 127, id = 1 / d (0 if d == 0),
+    q = round-half-to-even(x * id), the stored scale is f16(d).  x: [..., n] f32 -> (d f16 [..., n/32], q int8 [..., n/32, 32])."""
+    x = np.asarray(x, f32)
+    xb = x.reshape(x.shape[:-1] + (x.shape[-1] // 32, 32))
+    amax = np.abs(xb).max(axis=-1)
+    d = (amax / f32(127.0)).astype(f32)
+    with np.errstate(divide="ignore"):
+        idv = np.where(d != 0, (f32(1.0) / d).astype(f32), f32(0.0)).astype(f32)
+    qv = np.rint((xb * idv[..., None]).astype(f32)).astype(np.int8)
+    return d.astype(np.float16), qv
+
+
+def vec_dot_q8_0_q8_0_simd(kd: np.ndarray, kq: np.ndarray, qd: np.ndarray, qq: np.ndarray) -> np.ndarray:
+    """ggml_vec_dot_q8_0_q8_0 in its AVX2 form (ggml-cpu-quants.c:3597-…): rows kd [R, nb] f16 / kq [R, nb, 32] int8 against one quantized vector
+    qd [nb] f16 / qq [nb, 32] int8.  Per block d = f32(kd) * f32(qd); eight f32 lanes, lane l += fma(d, float(sum of products 4l..4l+3));
+    result hsum_float_8: t[i] = a[i] + a[i+4]; (t0 + t2) + (t1 + t3)."""
+    R, nb = kd.shape
+    acc = np.zeros((R, 8), f32)
+    for b in range(nb):
+        dd = (kd[:, b].astype(f32) * f32(qd[b])).astype(f32)
+        s4 = (kq[:, b].astype(np.int32) * qq[b].astype(np.int32)).reshape(R, 8, 4).sum(axis=-1).astype(f32)
+        acc = (dd[:, None].astype(np.float64) * s4.astype(np.float64) + acc.astype(np.float64)).astype(f32)
+    t = (acc[:, :4] + acc[:, 4:]).astype(f32)
+    return ((t[:, 0] + t[:, 2]).astype(f32) + (t[:, 1] + t[:, 3]).astype(f32)).astype(f32)
+
+
+def flash_attn_ext_q8_0(q: np.ndarray, k_blocks: np.ndarray, v_blocks: np.ndarray, mask: np.ndarray | None, scale: float, max_bias: float = 0.0,
+                        logit_softcap: float = 0.0) -> np.ndarray:
+    """FLASH_ATTN_EXT on a Q8_0 K / V cache (ops.cpp:6686-6905 with k->type = v->type = Q8_0).  q: [B, H, N, DK] f32; k_blocks / v_blocks: the cache rows
+    as stored, uint8 [B, Hk, n_kv, DK/32*34] (block_q8_0: f16 d, 32 int8).  The CPU quantizes q to Q8_0 (the K type's vec_dot_type; SIMD quantizer),
+    takes the scores with ggml_vec_dot_q8_0_q8_0, walks the positions in order with a running maximum, and keeps V.P in an F32 accumulator: V is
+    dequantized (q * d), the accumulator rescaled by an f32 multiply when the maximum grows and updated with an f32 fma per position."""
+    q = np.asarray(q, f32)
+    B, H, N, DK = q.shape
+    Hk, n_kv = k_blocks.shape[1], k_blocks.shape[2]
+    def unpack(blk):
+        nbk = blk.shape[-1] // 34
+        b = np.ascontiguousarray(blk).reshape(blk.shape[:-1] + (nbk, 34))
+        d = np.ascontiguousarray(b[..., :2]).view(np.float16)[..., 0]
+        return d, np.ascontiguousarray(b[..., 2:]).view(np.int8)
+    kd, kq = unpack(k_blocks); vd, vq = unpack(v_blocks)
+    DV = vq.shape[-2] * 32
+    n_head_log2 = 1 << int(np.floor(np.log2(H)))
+    m0 = f32(2.0) ** f32(-(max_bias) / n_head_log2); m1 = f32(2.0) ** f32(-(max_bias / 2.0) / n_head_log2)
+    sc = f32(scale)
+    if logit_softcap != 0.0:
+        sc = f32(sc / f32(logit_softcap))
+    out = np.zeros((B, N, H, DV), f32)
+    for b in range(B):
+        for h in range(H):
+            slope = f32(1.0)
+            if max_bias > 0.0:
+                slope = f32(m0 ** f32(h + 1)) if h < n_head_log2 else f32(m1 ** f32(2 * (h - n_head_log2) + 1))
+            hk = h // (H // Hk)
+            vdeq = (vq[b, hk].astype(f32) * vd[b, hk].astype(f32)[..., None]).astype(f32).reshape(n_kv, DV)      # dequantize_row_q8_0
+            for n in range(N):
+                qdn, qqn = quantize_row_q8_0_simd(q[b, h, n])
+                dots = vec_dot_q8_0_q8_0_simd(kd[b, hk], kq[b, hk], qdn, qqn)
+                S = f32(0.0); M = f32(-np.inf)
+                acc = np.zeros(DV, f32)
+                for j in range(n_kv):
+                    mv = f32(slope * f32(mask[n, j])) if mask is not None else f32(0.0)
+                    if mv == -np.inf:
+                        continue
+                    s = f32(dots[j] * sc)
+                    if logit_softcap != 0.0:
+                        s = f32(f32(logit_softcap) * f32(_libm.tanhf(float(s))))
+                    s = f32(s + mv)
+                    ms = f32(1.0); vs = f32(1.0)
+                    if s > M:
+                        Mold = M; M = s
+                        ms = _expf(f32(Mold - M))
+                        acc = (acc * ms).astype(f32)                                                        # ggml_vec_scale_f32
+                    else:
+                        vs = _expf(f32(s - M))
+                    acc = (vdeq[j].astype(np.float64) * np.float64(vs) + acc.astype(np.float64)).astype(f32)    # ggml_vec_mad_f32 (fma)
+                    S = f32(f32(S * ms) + vs)
+                out[b, n, h] = acc * f32(f32(1.0) / S)
+    return out

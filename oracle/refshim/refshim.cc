@@ -217,20 +217,29 @@ int ref_glue_op(int op, const float * a, const int64_t * ne_a, const float * b, 
     return st == GGML_STATUS_SUCCESS ? 0 : 2;
 }
 
-// FLASH_ATTN_EXT on the reference CPU backend (ggml-cpu/ops.cpp:6686-6905): q f32 [DK, N, H, B]; k / v given as f32 and stored as F16 [DK|DV, n_kv, Hk, B];
-// mask given as f32 [n_kv, n_pad] and stored as F16, or null.  out: f32 [DV, H, N, B].
-int ref_flash_attn_ext(const float * q, const int64_t * ne_q, const float * k, const int64_t * ne_k, const float * v, const int64_t * ne_v,
-                       const float * mask, int64_t n_pad, float scale, float max_bias, float softcap, float * out, int n_threads) {
+// FLASH_ATTN_EXT on the reference CPU backend (ggml-cpu/ops.cpp:6686-6905): q f32 [DK, N, H, B]; k / v given as f32 and stored in the cache type kv_type
+// (F16: rounded; quantized types: ggml_quantize_chunk, i.e. the reference quantizer) as [DK|DV, n_kv, Hk, B]; mask given as f32 [n_kv, n_pad] and stored
+// as F16, or null.  out: f32 [DV, H, N, B].  k_bytes / v_bytes (optional): the cache contents as stored, for the caller to hand to another implementation.
+int ref_flash_attn_ext_t(const float * q, const int64_t * ne_q, const float * k, const int64_t * ne_k, const float * v, const int64_t * ne_v,
+                         const float * mask, int64_t n_pad, float scale, float max_bias, float softcap, int kv_type, float * out, void * k_bytes, void * v_bytes, int n_threads) {
     const int64_t nq = ne_q[0] * ne_q[1] * ne_q[2] * ne_q[3], nk = ne_k[0] * ne_k[1] * ne_k[2] * ne_k[3], nv = ne_v[0] * ne_v[1] * ne_v[2] * ne_v[3];
     struct ggml_init_params ipar = { (size_t) (nq + nk + nv + ne_k[1] * n_pad) * 8 + (size_t) 256 * 1024 * 1024, nullptr, false };
     struct ggml_context * ctx = ggml_init(ipar);
     if (!ctx) return 1;
+    const ggml_type kvt = (ggml_type) kv_type;
     struct ggml_tensor * tq = ggml_new_tensor_4d(ctx, GGML_TYPE_F32, ne_q[0], ne_q[1], ne_q[2], ne_q[3]);
-    struct ggml_tensor * tk = ggml_new_tensor_4d(ctx, GGML_TYPE_F16, ne_k[0], ne_k[1], ne_k[2], ne_k[3]);
-    struct ggml_tensor * tv = ggml_new_tensor_4d(ctx, GGML_TYPE_F16, ne_v[0], ne_v[1], ne_v[2], ne_v[3]);
+    struct ggml_tensor * tk = ggml_new_tensor_4d(ctx, kvt, ne_k[0], ne_k[1], ne_k[2], ne_k[3]);
+    struct ggml_tensor * tv = ggml_new_tensor_4d(ctx, kvt, ne_v[0], ne_v[1], ne_v[2], ne_v[3]);
     memcpy(tq->data, q, (size_t) nq * 4);
-    ggml_fp32_to_fp16_row(k, (ggml_fp16_t *) tk->data, nk);
-    ggml_fp32_to_fp16_row(v, (ggml_fp16_t *) tv->data, nv);
+    if (kvt == GGML_TYPE_F16) {
+        ggml_fp32_to_fp16_row(k, (ggml_fp16_t *) tk->data, nk);
+        ggml_fp32_to_fp16_row(v, (ggml_fp16_t *) tv->data, nv);
+    } else {
+        ggml_quantize_chunk(kvt, k, tk->data, 0, nk / ne_k[0], ne_k[0], nullptr);
+        ggml_quantize_chunk(kvt, v, tv->data, 0, nv / ne_v[0], ne_v[0], nullptr);
+    }
+    if (k_bytes) memcpy(k_bytes, tk->data, ggml_nbytes(tk));
+    if (v_bytes) memcpy(v_bytes, tv->data, ggml_nbytes(tv));
     struct ggml_tensor * tm = nullptr;
     if (mask) {
         tm = ggml_new_tensor_2d(ctx, GGML_TYPE_F16, ne_k[1], n_pad);
@@ -243,6 +252,10 @@ int ref_flash_attn_ext(const float * q, const int64_t * ne_q, const float * k, c
     if (st == GGML_STATUS_SUCCESS) memcpy(out, c->data, ggml_nbytes(c));
     ggml_free(ctx);
     return st == GGML_STATUS_SUCCESS ? 0 : 2;
+}
+int ref_flash_attn_ext(const float * q, const int64_t * ne_q, const float * k, const int64_t * ne_k, const float * v, const int64_t * ne_v,
+                       const float * mask, int64_t n_pad, float scale, float max_bias, float softcap, float * out, int n_threads) {
+    return ref_flash_attn_ext_t(q, ne_q, k, ne_k, v, ne_v, mask, n_pad, scale, max_bias, softcap, (int) GGML_TYPE_F16, out, nullptr, nullptr, n_threads);
 }
 
 } // extern "C"

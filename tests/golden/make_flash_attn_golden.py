@@ -40,7 +40,19 @@ def main() -> None:
         assert np.isfinite(y).all()
         np.savez_compressed(OUT / f"flash_attn_{tag}.npz", q=q, k=k, v=v, mask=mask, scale=scale, max_bias=np.float32(max_bias),
                             softcap=np.float32(softcap), y=y)
-    print("wrote", len(CASES), "flash_attn fixtures to", OUT)
+    # the same op on a Q8_0 K / V cache (-ctk q8_0 -ctv q8_0): the cache rows as the reference quantizer stores them, and the CPU backend's output
+    for tag, (H, Hk, N, DK, n_kv, first_masked) in {"q8_0_decode_gqa_d128_kv256": (8, 2, 1, 128, 256, 201), "q8_0_batch3_d64_kv96": (4, 4, 3, 64, 96, 60)}.items():
+        rng = np.random.default_rng(sum(map(ord, tag)))
+        q = rng.standard_normal((1, H, N, DK)).astype(np.float32)
+        k = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float32); v = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float32)
+        mask = np.zeros((64, n_kv), np.float16)
+        for t in range(N):
+            mask[t, first_masked + t:] = -np.inf
+        scale = np.float32(1.0 / np.sqrt(DK))
+        y, kb, vb = ref.flash_attn_ext_q8_0(q, k, v, mask, float(scale))
+        assert np.isfinite(y).all()
+        np.savez_compressed(OUT / f"flash_attn_{tag}.npz", q=q, k_blocks=kb, v_blocks=vb, mask=mask, scale=scale, max_bias=np.float32(0), softcap=np.float32(0), y=y)
+    print("wrote", len(CASES) + 2, "flash_attn fixtures to", OUT)
 
 
 if __name__ == "__main__":

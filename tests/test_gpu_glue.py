@@ -5,6 +5,7 @@ import numpy as np
 from pathlib import Path
 import pytest
 
+import oracle
 from oracle import glue
 
 pytestmark = pytest.mark.gpu
@@ -302,7 +303,8 @@ def test_flash_attn_ext_has_the_cpu_bits(G, torch, path):
     F16 accumulator with its two roundings, the C library's expf -- so the outputs are the CPU's, bit for bit, except where a device tanhf / powf
     (soft-capping, ALiBi slopes) differs in the last place and flips one of the f16 roundings."""
     g = np.load(path, allow_pickle=False)
-    y = G.op_flash_attn_ext(dev(torch, g["q"]), dev(torch, g["k"]), dev(torch, g["v"]), dev(torch, g["mask"]), float(g["scale"]), float(g["max_bias"]),
+    kk, vv = (g["k_blocks"], g["v_blocks"]) if "k_blocks" in g else (g["k"], g["v"])       # (uint8 block rows: a Q8_0 cache)
+    y = G.op_flash_attn_ext(dev(torch, g["q"]), dev(torch, kk), dev(torch, vv), dev(torch, g["mask"]), float(g["scale"]), float(g["max_bias"]),
                             float(g["softcap"])).cpu().numpy()
     want = g["y"]
     assert np.isfinite(y).all()
@@ -312,3 +314,43 @@ def test_flash_attn_ext_has_the_cpu_bits(G, torch, path):
     differ = (y.view(np.uint32) != want.view(np.uint32)).mean()
     # (tanhf / powf one ulp off move every output of a head in the last place through the sum S; what must stay rare is a flipped f16 rounding)
     assert d.max() <= 2e-3 * top and (differ == 0.0 if plain else (d > 1e-6 * top).mean() <= 0.02), (d.max() / top, differ, (d > 1e-6 * top).mean())
+
+
+def test_cpy_f32_to_q8_0_is_the_reference_quantizer(G, torch):
+    """CPY f32 -> Q8_0 (the K / V stores of a quantized cache): block for block the bytes of quantize_row_q8_0_ref (oracle / the reference's
+    ggml_quantize_chunk), from a strided source."""
+    orc = oracle.Oracle()
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((3, 5, 256)) * rng.uniform(0.01, 20.0, (3, 5, 1))).astype(np.float32)
+    x[1, 2, 32:64] = 0.0                                                 # an all-zero block: d = 0, quants 0
+    big = dev(torch, np.concatenate([x, np.zeros_like(x)], axis=-1))     # rows with a gap: source stride 512 floats
+    src = big[..., :256]
+    out = torch.zeros((3, 5, 256 // 32 * 34), dtype=torch.uint8, device="cuda")
+    G.op_cpy(src, out)
+    want = orc.quantize_act(oracle.Q8_0, x.reshape(-1, 256))
+    assert np.array_equal(out.cpu().numpy().reshape(-1), np.ascontiguousarray(want).view(np.uint8).reshape(-1))
+
+
+@pytest.mark.parametrize("cfg", [(8, 2, 1, 128, 256, 201, 0.0), (4, 4, 3, 64, 96, 60, 0.0), (8, 8, 2, 128, 64, 55, 8.0), (2, 1, 1, 256, 40, 30, 0.0)], ids=str)
+def test_flash_attn_ext_q8_0_cache(G, torch, cfg):
+    """FLASH_ATTN_EXT on a Q8_0 K / V cache (-ctk q8_0 -ctv q8_0) against oracle.glue.flash_attn_ext_q8_0, which is bit-exact with the reference CPU
+    backend (tests/test_oracle_glue.py): q quantized to Q8_0, ggml_vec_dot_q8_0_q8_0's lane order, the online softmax in order, an F32 accumulator.
+    Plain cases: every output bit; with ALiBi (device powf) within the last place.  The cache rows are written by the device's own CPY."""
+    H, Hk, N, DK, n_kv, first_masked, max_bias = cfg
+    rng = np.random.default_rng(sum(cfg[:6]))
+    q = rng.standard_normal((1, H, N, DK)).astype(np.float32)
+    kf = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float32); vf = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float32)
+    kb = torch.zeros((1, Hk, n_kv, DK // 32 * 34), dtype=torch.uint8, device="cuda"); vb = torch.zeros_like(kb)
+    G.op_cpy(dev(torch, kf), kb); G.op_cpy(dev(torch, vf), vb)
+    mask = np.zeros((64, n_kv), np.float16)
+    for t in range(N):
+        mask[t, first_masked + t:] = -np.inf
+    if max_bias > 0:
+        mask[:N] += (rng.standard_normal((N, n_kv)) * 0.1).astype(np.float16)
+    scale = float(np.float32(1.0 / np.sqrt(DK)))
+    y = G.op_flash_attn_ext(dev(torch, q), kb, vb, dev(torch, mask), scale, max_bias, 0.0).cpu().numpy()
+    want = glue.flash_attn_ext_q8_0(q, kb.cpu().numpy(), vb.cpu().numpy(), mask, scale, max_bias, 0.0)
+    assert np.isfinite(y).all()
+    d = np.abs(y.astype(np.float64) - want); top = np.abs(want).max()
+    differ = (y.view(np.uint32) != want.view(np.uint32)).mean()
+    assert d.max() <= 1e-5 * top and (differ == 0.0 if max_bias == 0.0 else True), (cfg, d.max() / top, differ)

@@ -89,5 +89,8 @@ def test_flash_attn_ext_golden(path):
     """oracle/glue.py flash_attn_ext against the reference CPU backend's FLASH_ATTN_EXT (fixtures: tests/golden/make_flash_attn_golden.py), bit for bit."""
     from oracle import glue
     g = np.load(path, allow_pickle=False)
-    got = glue.flash_attn_ext(g["q"], g["k"], g["v"], g["mask"], float(g["scale"]), float(g["max_bias"]), float(g["softcap"]))
+    if "k_blocks" in g:                                              # a Q8_0 cache
+        got = glue.flash_attn_ext_q8_0(g["q"], g["k_blocks"], g["v_blocks"], g["mask"], float(g["scale"]), float(g["max_bias"]), float(g["softcap"]))
+    else:
+        got = glue.flash_attn_ext(g["q"], g["k"], g["v"], g["mask"], float(g["scale"]), float(g["max_bias"]), float(g["softcap"]))
     assert np.array_equal(got.view(np.uint32), g["y"].view(np.uint32))
