@@ -39,6 +39,7 @@
 #include <chrono>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #define MI355_MAX_DEVICES 16

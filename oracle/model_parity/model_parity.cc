@@ -44,7 +44,7 @@
 #include "ggml-alloc.h"
 #include "ggml-backend.h"
 
-struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; int n_expert = 0, n_used = 0; bool last_only = false;
+struct Dims { int n_embd = 2048, n_head = 16, n_head_kv = 4, hd = 128, n_ff = 4096, n_layer = 4, n_vocab = 32000, n_ctx = 256; bool fa = false; bool mask_cast = false; int n_expert = 0, n_used = 0; bool last_only = false;
               ggml_type wtype = GGML_TYPE_Q4_K, wtype_more = GGML_TYPE_Q6_K; };      // the recipe's main type and its "more bits" type (--wtype)
 
 struct Layer { ggml_tensor *attn_norm, *ffn_norm, *wq, *wk, *wv, *wo, *wgate, *wup, *wdown, *kc, *vc, *gate_inp; };   // MoE: wgate / wup / wdown are [k, m, n_expert]
@@ -110,7 +110,9 @@ static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens
     const int n_kv = S.n_kv = GGML_PAD(n_past + n_tokens, d.fa ? 256 : 32);
     S.x    = ggml_new_tensor_2d(c, GGML_TYPE_F32, d.n_embd, n_tokens);  ggml_set_input(S.x);
     S.pos  = ggml_new_tensor_1d(c, GGML_TYPE_I32, n_tokens);            ggml_set_input(S.pos);
-    S.mask = ggml_new_tensor_2d(c, d.fa ? GGML_TYPE_F16 : GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, d.fa ? 64 : 32)); ggml_set_input(S.mask);
+    // (--mask-cast: the mask input is f32 and FLASH_ATTN_EXT gets an F16 copy made inside the graph, as libllama does: llama-graph.cpp, ggml_cast(self_kq_mask, F16))
+    S.mask = ggml_new_tensor_2d(c, d.fa && !d.mask_cast ? GGML_TYPE_F16 : GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, d.fa ? 64 : 32)); ggml_set_input(S.mask);
+    ggml_tensor * fa_mask = d.fa && d.mask_cast ? ggml_cast(c, S.mask, GGML_TYPE_F16) : S.mask;
     // the rows the output norm / matrix are computed for (llm_graph_context::build_inp_out_ids): every row of a compared prompt, else the last one
     S.n_out = (d.last_only || n_tokens == 1) ? 1 : n_tokens;
     S.out_ids = ggml_new_tensor_1d(c, GGML_TYPE_I32, S.n_out);           ggml_set_input(S.out_ids);
@@ -133,7 +135,7 @@ static Step build_step(const Dims & d, const Model & M, int n_past, int n_tokens
             ggml_tensor * v_view = ggml_view_1d(c, L.vc, (int64_t) n_tokens * n_embd_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv) * n_past);
             ggml_build_forward_expand(S.gf, ggml_cpy(c, ggml_reshape_2d(c, V, n_embd_kv, n_tokens), v_view));
             ggml_tensor * v = ggml_view_3d(c, L.vc, d.hd, n_kv, d.n_head_kv, ggml_row_size(GGML_TYPE_F16, n_embd_kv), ggml_row_size(GGML_TYPE_F16, d.hd), 0);
-            cur = ggml_flash_attn_ext(c, q, k, v, S.mask, kq_scale, 0.0f, 0.0f);
+            cur = ggml_flash_attn_ext(c, q, k, v, fa_mask, kq_scale, 0.0f, 0.0f);
             ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
             cur = ggml_reshape_2d(c, cur, d.n_embd, n_tokens);
         } else {
@@ -221,7 +223,7 @@ int main(int argc, char ** argv) {
         auto next = [&]() { return i + 1 < argc ? std::string(argv[++i]) : std::string(); };
         if (a == "--preset") preset = next(); else if (a == "--layers") d.n_layer = atoi(next().c_str()); else if (a == "--vocab") d.n_vocab = atoi(next().c_str());
         else if (a == "--tokens") tokens = atoi(next().c_str()); else if (a == "--prompt") prompt = atoi(next().c_str()); else if (a == "--devs") devs = next();
-        else if (a == "--fa") d.fa = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--noise") noise = next(); else if (a == "--bench") bench = atoi(next().c_str()); else if (a == "--pp") pp = atoi(next().c_str());
+        else if (a == "--fa") d.fa = true; else if (a == "--mask-cast") d.mask_cast = true; else if (a == "--dump") dump = next(); else if (a == "--check") check = next(); else if (a == "--noise") noise = next(); else if (a == "--bench") bench = atoi(next().c_str()); else if (a == "--pp") pp = atoi(next().c_str());
         else if (a == "--wtype") { const std::string v = next();            // q4_k_m (default), iq4_xs (IQ4_XS + Q5_K), iq4_nl (IQ4_NL + Q5_K), q8_0, q5_k_m (Q5_K + Q6_K), q3_k (Q3_K + Q5_K)
             if (v == "iq4_xs") { d.wtype = GGML_TYPE_IQ4_XS; d.wtype_more = GGML_TYPE_Q5_K; } else if (v == "iq4_nl") { d.wtype = GGML_TYPE_IQ4_NL; d.wtype_more = GGML_TYPE_Q5_K; }
             else if (v == "q8_0") { d.wtype = d.wtype_more = GGML_TYPE_Q8_0; } else if (v == "q5_k_m") { d.wtype = GGML_TYPE_Q5_K; d.wtype_more = GGML_TYPE_Q6_K; }
@@ -366,7 +368,7 @@ int main(int argc, char ** argv) {
         const int rows = GGML_PAD(n, d.fa ? 64 : 32);
         std::vector<float> m((size_t) S.n_kv * rows, -INFINITY);
         for (int i = 0; i < n; ++i) for (int j = 0; j <= n_past + i; ++j) m[(size_t) i * S.n_kv + j] = 0.0f;
-        if (d.fa) { std::vector<ggml_fp16_t> h(m.size()); ggml_fp32_to_fp16_row(m.data(), h.data(), m.size()); ggml_backend_tensor_set(S.mask, h.data(), 0, h.size() * 2); }
+        if (d.fa && !d.mask_cast) { std::vector<ggml_fp16_t> h(m.size()); ggml_fp32_to_fp16_row(m.data(), h.data(), m.size()); ggml_backend_tensor_set(S.mask, h.data(), 0, h.size() * 2); }
         else ggml_backend_tensor_set(S.mask, m.data(), 0, m.size() * 4);
         std::vector<int32_t> oi((size_t) S.n_out); for (int i = 0; i < S.n_out; ++i) oi[(size_t) i] = S.n_out == n ? i : n - 1;
         if (S.out_ids->buffer) ggml_backend_tensor_set(S.out_ids, oi.data(), 0, oi.size() * 4);      // (a graph without the model's head does not use it: not allocated)

@@ -369,6 +369,25 @@ def test_moe_model_resident_and_equal_to_cpu():
 
 @pytest.mark.gpu
 @needs_plugin
+def test_libllama_flash_graph_with_its_mask_copy_is_planned():
+    """libllama gives FLASH_ATTN_EXT an F16 COPY of its f32 mask input, one CPY node per graph emitted inside the first layer (llama-graph.cpp:
+    ggml_cast(self_kq_mask, F16)).  Left uncovered it is a hole in the middle of the plan and every stage behind it is dropped -- llama-bench -fa 1 ran
+    node by node at 185 tok/s until the matcher read the f32 source instead and elided the copy (419 tok/s).  model_parity --mask-cast builds the graph
+    that way: every decode step must run as one launch and match the CPU."""
+    if _model_parity() is None or not _model_parity().exists():
+        pytest.skip("oracle/_ref/*/model_parity not built")
+    r = _run_model(["--preset", "small", "--layers", "4", "--vocab", "8192", "--tokens", "8", "--fa", "--mask-cast"])
+    print(r.stdout[-1500:], r.stderr[-400:])
+    assert "0 refused by MI355_0" in r.stdout
+    planned, built = _planned(r.stderr)
+    assert planned == 8 and built == 1, (planned, built)
+    m = re.search(r"worst logits NMSE ([0-9.e+-]+), worst max\|d\|/max\|ref\| ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(1)) <= CHAOS_NMSE and float(m.group(2)) <= CHAOS_REL, r.stdout[-2000:]
+    assert "ARGMAX DIFFERS" not in r.stdout
+
+
+@pytest.mark.gpu
+@needs_plugin
 @pytest.mark.parametrize("plan", [True, False], ids=["plan", "node_by_node"])
 def test_teacher_forced_layers(plan):
     """The north-star bound where chaos cannot hide a bug: after 4 ordinary decode steps, for 4 more tokens the reference CPU backend evaluates the whole
