@@ -359,8 +359,8 @@ def llama_bench_leg(reps=2, threads=16, timeout_s=420):
         r = subprocess.run([str(synth), "--preset", "8b", "--ftype", "q4_k_m", "--out", str(gguf)], capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             return {"error": "gguf_synth failed", "tail": (r.stdout + r.stderr)[-300:]}
-    def run(ngl, env, r_):
-        cmd = [str(exe), "-m", str(gguf), "-p", "512", "-n", "128", "-r", str(r_), "-ngl", str(ngl), "-t", str(threads), "-o", "json"]
+    def run(ngl, env, r_, extra=(), p="512"):
+        cmd = [str(exe), "-m", str(gguf), "-p", p, "-n", "128", "-r", str(r_), "-ngl", str(ngl), "-t", str(threads), "-o", "json"] + list(extra)
         pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         if pr.returncode != 0:
             return None, pr
@@ -382,6 +382,14 @@ def llama_bench_leg(reps=2, threads=16, timeout_s=420):
         gpu["graph_compute_calls_as_one_launch"] = sum(int(a_) for a_, _ in plans) if plans else None      # expected: (reps + warm-up) x 128 + warm-up tokens
         gpu["plans_built"] = sum(int(b_) for _, b_ in plans) if plans else None
         out["ngl99"] = gpu
+        # the other attention forms of the same run: -fa 1 (FLASH_ATTN_EXT: one launch per token, the CPU's F16 accumulator) and a Q8_0 KV cache (resident, node path)
+        for key, extra in (("ngl99_fa1", ["-fa", "1"]), ("ngl99_fa1_kv_q8_0", ["-fa", "1", "-ctk", "q8_0", "-ctv", "q8_0"])):
+            r2, pr2 = run(99, env_gpu, 1, extra, p="0")
+            if r2 is None:
+                out[key] = {"error": f"exit {pr2.returncode}", "tail": (pr2.stdout + pr2.stderr)[-300:]}
+            else:
+                pl2 = re.findall(r"MI355 decode plans: (\d+) graph_compute calls ran as one persistent launch, (\d+) plans built", pr2.stderr)
+                out[key] = {"tg128": r2.get("tg128"), "graph_compute_calls_as_one_launch": sum(int(a_) for a_, _ in pl2) if pl2 else None}
     env_cpu = {k: v for k, v in os.environ.items() if k != "GGML_BACKEND_PATH"}
     cpu, pr = run(0, env_cpu, 1)
     out["ngl0_cpu"] = cpu if cpu is not None else {"error": f"exit {pr.returncode}", "tail": (pr.stdout + pr.stderr)[-400:]}
