@@ -114,11 +114,11 @@ static bool mi355_is_quant(enum ggml_type t) { return mi355q_type_supported((int
 // the tensor whose shape defines the device row layout (views share their source's rows)
 static const struct ggml_tensor * mi355_root(const struct ggml_tensor * t) { return t->view_src ? t->view_src : t; }
 
-// A Q8_0 tensor outside a weight buffer is (or may become) a KV cache (-ctk q8_0 / -ctv q8_0): the device writes its rows block by block (CPY) and the
+// A Q8_0 / Q4_0 tensor outside a weight buffer is (or may become) a KV cache (-ctk q8_0 / q4_0, -ctv ...): the device writes its rows block by block (CPY) and the
 // attention kernel reads heads out of them, so it keeps the CANONICAL block order; only Q8_0 tensors in buffers the application marked as weights are planar.
 static bool mi355_q80_canonical(const struct ggml_tensor * t) {
     const struct ggml_tensor * r = mi355_root(t);
-    return t->type == GGML_TYPE_Q8_0 && !(r->buffer && r->buffer->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+    return (t->type == GGML_TYPE_Q8_0 || t->type == GGML_TYPE_Q4_0) && !(r->buffer && r->buffer->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
 }
 // rows of a quantized tensor are stored planar iff (type, ne0, and for Q8_0 the buffer's usage) say so -- same predicate everywhere
 static bool mi355_rows_planar(const struct ggml_tensor * t) {
@@ -193,7 +193,7 @@ static bool mi355_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct g
     // device-to-device only when both sides keep the same byte image (same type and row length)
     if (!mi355_buffer_is_ours(src->buffer)) return false;
     if (src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst) || ggml_nbytes(src) != ggml_nbytes(dst)) return false;
-    if (mi355_is_quant(src->type) && mi355_root(src)->ne[0] != mi355_root(dst)->ne[0]) return false;
+    if (mi355_is_quant(src->type) && (mi355_root(src)->ne[0] != mi355_root(dst)->ne[0] || mi355_rows_planar(src) != mi355_rows_planar(dst))) return false;   // (a Q8_0 tensor is planar in a weight buffer only)
     mi355_buffer_ctx * ctx = (mi355_buffer_ctx *) buffer->context;
     mi355q_set_device(ctx->device);
     MQ_CHECK(mi355q_memcpy_d2d(dst->data, src->data, ggml_nbytes(src), nullptr));
@@ -373,7 +373,7 @@ static void mi355_backend_synchronize(ggml_backend_t backend) {
 // ---- residency ops: thin wrappers over mi355q_op_* -- the tensor descriptor is ggml's ne[] / nb[] verbatim
 static mi355q_tensor mi355_td(const struct ggml_tensor * t) {
     mi355q_tensor d;
-    d.data = t->data; d.type = t->type == GGML_TYPE_F16 ? MI355Q_T_F16 : t->type == GGML_TYPE_Q8_0 ? MI355Q_TYPE_Q8_0 : MI355Q_T_F32;     // (Q8_0: a quantized KV cache, CPY destination / FLASH_ATTN_EXT operand)
+    d.data = t->data; d.type = t->type == GGML_TYPE_F16 ? MI355Q_T_F16 : t->type == GGML_TYPE_Q8_0 ? MI355Q_TYPE_Q8_0 : t->type == GGML_TYPE_Q4_0 ? MI355Q_TYPE_Q4_0 : MI355Q_T_F32;     // (Q8_0: a quantized KV cache, CPY destination / FLASH_ATTN_EXT operand)
     for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t) t->nb[i]; }
     return d;
 }
@@ -872,7 +872,7 @@ static bool mi355_backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_back
     struct ggml_backend_buffer * bs = src->view_src ? src->view_src->buffer : src->buffer;
     struct ggml_backend_buffer * bd = dst->view_src ? dst->view_src->buffer : dst->buffer;
     if (!mi355_buffer_is_ours(bs) || !mi355_buffer_is_ours(bd)) return false;
-    if (mi355_is_quant(src->type) && mi355_root(src)->ne[0] != mi355_root(dst)->ne[0]) return false;   // (device rows of another row length are laid out differently)
+    if (mi355_is_quant(src->type) && (mi355_root(src)->ne[0] != mi355_root(dst)->ne[0] || mi355_rows_planar(src) != mi355_rows_planar(dst))) return false;   // (device rows of another row length, or of a weight / non-weight Q8_0 pair, are laid out differently)
     mi355_backend_ctx * cs = (mi355_backend_ctx *) backend_src->context, * cd = (mi355_backend_ctx *) backend_dst->context;
     const int dev_s = ((mi355_buffer_ctx *) bs->context)->device, dev_d = ((mi355_buffer_ctx *) bd->context)->device;
     if (dev_s != cs->device || dev_d != cd->device) return false;
@@ -1019,7 +1019,7 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
     }
     case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
         const struct ggml_tensor * a = op->src[0];
-        if (op->op == GGML_OP_CPY && op->type == GGML_TYPE_Q8_0)      // the K / V stores of a quantized cache (-ctk q8_0 -ctv q8_0): whole blocks, contiguous destination
+        if (op->op == GGML_OP_CPY && (op->type == GGML_TYPE_Q8_0 || op->type == GGML_TYPE_Q4_0))      // the K / V stores of a quantized cache (-ctk q8_0 / q4_0): whole blocks, contiguous destination
             return a->type == GGML_TYPE_F32 && mi355_operand_ok(a) && a->nb[0] == sizeof(float) && a->ne[0] % 32 == 0 && op->ne[0] % 32 == 0 &&
                    ggml_is_contiguous(op) && ggml_nelements(a) == ggml_nelements(op) && mi355_q80_canonical(op);
         return mi355_f32_or_f16(a->type) && mi355_f32_or_f16(op->type) && mi355_operand_ok(a) && ggml_nelements(a) == ggml_nelements(op);
@@ -1051,10 +1051,11 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const struct ggml_tens
     }
     case GGML_OP_FLASH_ATTN_EXT: {                            // f16 or Q8_0 KV cache, f32 queries, f16 mask; other cache types stay on the CPU
         const struct ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
-        const bool kv_q80 = k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0;       // a Q8_0 cache: the one-workgroup-per-row kernel with the CPU's arithmetic
+        const bool kv_q80 = (k->type == GGML_TYPE_Q8_0 && v->type == GGML_TYPE_Q8_0) || (k->type == GGML_TYPE_Q4_0 && v->type == GGML_TYPE_Q4_0);       // a Q8_0 / Q4_0 cache: the one-workgroup-per-row kernel with the CPU's arithmetic
+        const size_t kv_bb = k->type == GGML_TYPE_Q4_0 ? 18u : 34u;
         if (q->type != GGML_TYPE_F32 || !((k->type == GGML_TYPE_F16 && v->type == GGML_TYPE_F16) || kv_q80) || op->type != GGML_TYPE_F32) return false;
         if (!mi355_operand_ok(q) || !mi355_operand_ok(k) || !mi355_operand_ok(v) || (m && !mi355_operand_ok(m))) return false;
-        if (q->nb[0] != 4 || k->nb[0] != (kv_q80 ? 34u : 2u) || v->nb[0] != (kv_q80 ? 34u : 2u) || !ggml_is_contiguous(op)) return false;
+        if (q->nb[0] != 4 || k->nb[0] != (kv_q80 ? kv_bb : 2u) || v->nb[0] != (kv_q80 ? kv_bb : 2u) || !ggml_is_contiguous(op)) return false;
         if (kv_q80 && (k->ne[0] % 32 || v->ne[0] % 32 || k->ne[1] > 8192 || !mi355_q80_canonical(k) || !mi355_q80_canonical(v))) return false;
         if (m && (m->type != GGML_TYPE_F16 || m->nb[0] != 2 || m->ne[0] < k->ne[1] || m->ne[1] < q->ne[1] || m->ne[2] != 1 || m->ne[3] != 1)) return false;
         return k->ne[0] <= 256 && v->ne[0] <= 256 && k->ne[1] >= 1 && k->ne[1] <= 36864 && q->ne[2] <= 65535 && q->ne[3] <= 65535;

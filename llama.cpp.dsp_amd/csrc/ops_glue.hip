@@ -287,6 +287,39 @@ __global__ void __launch_bounds__(256) k_cpy_f32_q8_0(const TensorD a, char * ds
     }
 }
 
+// CPY f32 -> Q4_0 (a Q4_0 cache): quantize_row_q4_0_ref (ggml-quants.c:31-66) -- max = the FIRST element of largest magnitude, signed; d = max / -8;
+// q = min(15, (int8) (x / d + 8.5)); byte j = q[j] | q[j + 16] << 4.  Eight lanes own a block (lane l: elements 4l .. 4l+3).
+__global__ void __launch_bounds__(256) k_cpy_f32_q4_0(const TensorD a, char * dst, int64_t n_blocks, char * const * dest_table, int dest_index) {
+    if (dest_table) dst = dest_table[dest_index];
+    const int lane = threadIdx.x & 63, lane8 = lane & 7;
+    for (int64_t b0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 3; b0 < ((n_blocks + 31) & ~(int64_t) 31); b0 += ((int64_t) gridDim.x * blockDim.x) >> 3) {
+        const int64_t b = b0 < n_blocks ? b0 : n_blocks - 1;
+        const int64_t e = 32 * b + 4 * lane8;
+        const int64_t a0 = e % a.ne[0], ar = e / a.ne[0], a1 = ar % a.ne[1], ar2 = ar / a.ne[1], a2 = ar2 % a.ne[2], a3 = ar2 / a.ne[2];
+        const float * src = (const float *) (a.data + a0 * 4 + a1 * a.nb[1] + a2 * a.nb[2] + a3 * a.nb[3]);
+        const float x[4] = { src[0], src[1], src[2], src[3] };
+        float amax = 0.0f, mx = 0.0f;                            // this lane's first element of largest magnitude
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (amax < fabsf(x[i])) { amax = fabsf(x[i]); mx = x[i]; }
+        const float gmax = oct_max(amax);                         // the block's largest magnitude; its first holder is the lowest lane that has it
+        const unsigned long long holders = __ballot(amax == gmax);
+        const int first = __ffs((int) ((holders >> (lane & ~7)) & 0xFFull)) - 1;
+        const float bmax = __shfl(mx, (lane & ~7) + first, 64);
+        const float d = __fdiv_rn(bmax, -8.0f), id = d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f;
+        uint32_t nib = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int qi = min(15, (int) (int8_t) __fadd_rn(__fmul_rn(x[i], id), 8.5f)); nib |= (uint32_t) (qi & 0xFF) << (8 * i); }
+        const uint32_t hi = (uint32_t) dpp_i<0x104>((int) nib);  // row_shl:4 -- lanes 0..3 of the group get elements 16..31 from lanes 4..7
+        if (b0 < n_blocks && lane8 < 4) {
+            char * blk = dst + 18 * b;
+            const uint32_t w = (nib & 0x0F0F0F0Fu) | ((hi & 0x0F0F0F0Fu) << 4);
+            if (lane8 == 0) *(__half *) blk = __float2half_rn(d);
+            *(uint16_t *) (blk + 2 + 4 * lane8) = (uint16_t) (w & 0xFFFFu);
+            *(uint16_t *) (blk + 4 + 4 * lane8) = (uint16_t) (w >> 16);
+        }
+    }
+}
+
 static bool cpy_fast(const mi355q_tensor * a, const mi355q_tensor * d, char * const * table, int index, hipStream_t st) {
     const int64_t n = nelements(d);
     if (n < 16384) return false;
@@ -656,9 +689,11 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext(const TensorD q, 
 // ggml_vec_dot_q8_0_q8_0 in its AVX2 order (per block d = d_k * d_q, eight f32 lane sums of four int8 products each fed by fma, hsum tree), the online
 // softmax walked in order (prefix maximum, as in k_flash_attn_ext's seq mode), V dequantized (q * d) into an F32 accumulator: scale by f32 multiply when
 // the maximum grows, v * weight by f32 fma per position (ggml_vec_scale_f32 / ggml_vec_mad_f32).
+template <int KVT>                                                          // MI355Q_TYPE_Q8_0 (34-byte blocks) or MI355Q_TYPE_Q4_0 (18-byte blocks: f16 d, 16 bytes of nibbles, low = elements 0..15)
 __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext_q80(const TensorD q, const TensorD k, const TensorD v, const TensorD m, int has_mask, const TensorD d,
                                                                    float scale, float max_bias, float softcap, float m0, float m1, uint32_t n_head_log2) {
     extern __shared__ __attribute__((aligned(16))) float fq_s[];             // [n_kv] scores -> weights | [n_kv] rescale factors | q: [DK / 32] block scales, [DK / 4] packed quants
+    constexpr int BB = KVT == MI355Q_TYPE_Q8_0 ? 34 : 18;                      // bytes per 32-element block of the cache
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int64_t DK = k.ne[0], DV = v.ne[0], n_kv = k.ne[1];
@@ -686,12 +721,23 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext_q80(const TensorD
             const char * row = k.data + j * k.nb[1] + hk * k.nb[2] + bk * k.nb[3];
             float acc[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
             for (int blk = 0; blk < nblk; ++blk) {
-                const char * kb = row + 34 * blk;
+                const char * kb = row + BB * blk;
                 const float dd = __fmul_rn(__half2float(*(const __half *) kb), qd[blk]);
+                if constexpr (KVT == MI355Q_TYPE_Q8_0) {
 #pragma unroll
-                for (int l = 0; l < 8; ++l) {
-                    const uint32_t kw = (uint32_t) *(const uint16_t *) (kb + 2 + 4 * l) | ((uint32_t) *(const uint16_t *) (kb + 4 + 4 * l) << 16);
-                    acc[l] = __builtin_fmaf(dd, (float) dot4((int) kw, (int) qq[8 * blk + l], 0), acc[l]);
+                    for (int l = 0; l < 8; ++l) {
+                        const uint32_t kw = (uint32_t) *(const uint16_t *) (kb + 2 + 4 * l) | ((uint32_t) *(const uint16_t *) (kb + 4 + 4 * l) << 16);
+                        acc[l] = __builtin_fmaf(dd, (float) dot4((int) kw, (int) qq[8 * blk + l], 0), acc[l]);
+                    }
+                } else {
+                    // ggml_vec_dot_q4_0_q8_0 (AVX2): bytes_from_nibbles_32 puts the low nibbles at elements 0..15 and the high ones at 16..31, minus 8 each
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        const uint32_t kw = (uint32_t) *(const uint16_t *) (kb + 2 + 4 * l) | ((uint32_t) *(const uint16_t *) (kb + 4 + 4 * l) << 16);
+                        const int qlo = (int) qq[8 * blk + l], qhi = (int) qq[8 * blk + 4 + l];
+                        acc[l]     = __builtin_fmaf(dd, (float) (dot4((int) (kw & 0x0F0F0F0Fu), qlo, 0) - 8 * dot4(0x01010101, qlo, 0)), acc[l]);
+                        acc[l + 4] = __builtin_fmaf(dd, (float) (dot4((int) ((kw >> 4) & 0x0F0F0F0Fu), qhi, 0) - 8 * dot4(0x01010101, qhi, 0)), acc[l + 4]);
+                    }
                 }
             }
             const float t0 = __fadd_rn(acc[0], acc[4]), t1 = __fadd_rn(acc[1], acc[5]), t2 = __fadd_rn(acc[2], acc[6]), t3 = __fadd_rn(acc[3], acc[7]);
@@ -724,7 +770,7 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext_q80(const TensorD
     __syncthreads();
     // ---- V . P in an F32 accumulator, a thread per output dim
     if (tid < DV) {
-        const char * vb = v.data + hv * v.nb[2] + bv * v.nb[3] + 34 * (tid >> 5);
+        const char * vb = v.data + hv * v.nb[2] + bv * v.nb[3] + BB * (tid >> 5);
         const int e = tid & 31;
         float acc = 0.0f, S = 0.0f;
 #pragma unroll 4
@@ -732,7 +778,10 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext_q80(const TensorD
             const float vs = fq_s[j], ms = msv[j];
             if (vs != 0.0f || ms != 1.0f) {                                   // (uniform)
                 const char * blk = vb + j * v.nb[1];
-                const float vv = __fmul_rn((float) (int) *(const int8_t *) (blk + 2 + e), __half2float(*(const __half *) blk));     // dequantize_row_q8_0
+                int qv;
+                if constexpr (KVT == MI355Q_TYPE_Q8_0) qv = (int) *(const int8_t *) (blk + 2 + e);
+                else { const int byte = (int) *(const uint8_t *) (blk + 2 + (e & 15)); qv = ((e < 16 ? byte : byte >> 4) & 15) - 8; }
+                const float vv = __fmul_rn((float) qv, __half2float(*(const __half *) blk));     // dequantize_row_q8_0 / _q4_0
                 if (ms != 1.0f) acc = __fmul_rn(acc, ms);                     // ggml_vec_scale_f32
                 acc = __builtin_fmaf(vv, vs, acc);                            // ggml_vec_mad_f32
                 S = __fadd_rn(__fmul_rn(S, ms), vs);
@@ -1003,17 +1052,19 @@ int mi355q_op_unary_mul(int uop, const mi355q_tensor * a, const mi355q_tensor * 
 // f32 -> Q8_0: contiguous destination, source rows of whole blocks with unit stride along dim 0 (what ggml_compute_forward_dup_f32 requires too)
 static int cpy_to_q8_0(const mi355q_tensor * a, const mi355q_tensor * dst, char * const * table, int index, hipStream_t st) {
     const int64_t n = nelements(dst);
-    if (a->type != 0 || a->nb[0] != 4 || a->ne[0] % 32 != 0 || dst->ne[0] % 32 != 0 || dst->nb[0] != 34) return MI355Q_ERR_UNSUPPORTED;
-    if (dst->nb[1] != dst->ne[0] / 32 * 34 || dst->nb[2] != dst->nb[1] * dst->ne[1] || dst->nb[3] != dst->nb[2] * dst->ne[2]) return MI355Q_ERR_UNSUPPORTED;
+    const int bb = dst->type == MI355Q_TYPE_Q8_0 ? 34 : 18;     // (Q8_0 or Q4_0 blocks)
+    if (a->type != 0 || a->nb[0] != 4 || a->ne[0] % 32 != 0 || dst->ne[0] % 32 != 0 || dst->nb[0] != bb) return MI355Q_ERR_UNSUPPORTED;
+    if (dst->nb[1] != dst->ne[0] / 32 * bb || dst->nb[2] != dst->nb[1] * dst->ne[1] || dst->nb[3] != dst->nb[2] * dst->ne[2]) return MI355Q_ERR_UNSUPPORTED;
     if (n == 0) return MI355Q_OK;
-    hipLaunchKernelGGL(k_cpy_f32_q8_0, dim3(grid_for(n / 4)), dim3(256), 0, st, to_d(a), (char *) dst->data, n / 32, table, index);
+    if (dst->type == MI355Q_TYPE_Q8_0) hipLaunchKernelGGL(k_cpy_f32_q8_0, dim3(grid_for(n / 4)), dim3(256), 0, st, to_d(a), (char *) dst->data, n / 32, table, index);
+    else                               hipLaunchKernelGGL(k_cpy_f32_q4_0, dim3(grid_for(n / 4)), dim3(256), 0, st, to_d(a), (char *) dst->data, n / 32, table, index);
     return MI355Q_OK;
 }
 
 int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * stream) {
     if (!a || !dst || nelements(a) != nelements(dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_cpy: element counts differ");
-    if (dst->type == MI355Q_TYPE_Q8_0) {
-        if (cpy_to_q8_0(a, dst, nullptr, 0, (hipStream_t) stream) != MI355Q_OK) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 -> q8_0 needs a contiguous destination and source rows of whole 32-blocks");
+    if (dst->type == MI355Q_TYPE_Q8_0 || dst->type == MI355Q_TYPE_Q4_0) {
+        if (cpy_to_q8_0(a, dst, nullptr, 0, (hipStream_t) stream) != MI355Q_OK) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 -> q8_0 / q4_0 needs a contiguous destination and source rows of whole 32-blocks");
         OPS_LAUNCHED();
     }
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy: f32 / f16 only");
@@ -1026,8 +1077,8 @@ int mi355q_op_cpy(const mi355q_tensor * a, const mi355q_tensor * dst, void * str
 
 int mi355q_op_cpy_indirect(const mi355q_tensor * a, const mi355q_tensor * dst, void * const * dest_table, int index, void * stream) {
     if (!a || !dst || !dest_table || index < 0 || nelements(a) != nelements(dst)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_cpy_indirect: arguments");
-    if (dst->type == MI355Q_TYPE_Q8_0) {
-        if (cpy_to_q8_0(a, dst, (char * const *) dest_table, index, (hipStream_t) stream) != MI355Q_OK) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 -> q8_0 needs a contiguous destination and source rows of whole 32-blocks");
+    if (dst->type == MI355Q_TYPE_Q8_0 || dst->type == MI355Q_TYPE_Q4_0) {
+        if (cpy_to_q8_0(a, dst, (char * const *) dest_table, index, (hipStream_t) stream) != MI355Q_OK) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 -> q8_0 / q4_0 needs a contiguous destination and source rows of whole 32-blocks");
         OPS_LAUNCHED();
     }
     if (a->type < 0 || a->type > 1 || dst->type < 0 || dst->type > 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_cpy_indirect: f32 / f16 only");
@@ -1190,13 +1241,14 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
                              const mi355q_tensor * dst, float scale, float max_bias, float logit_softcap,
                              void * workspace, size_t workspace_bytes, void * stream) {
     if (!q || !k || !v || !dst) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: null tensor");
-    const bool kv_q80 = k->type == MI355Q_TYPE_Q8_0 && v->type == MI355Q_TYPE_Q8_0;
-    if (q->type != 0 || !((k->type == 1 && v->type == 1) || kv_q80) || dst->type != 0 || (mask && mask->type != 1)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q f32, k / v both f16 or both q8_0, mask f16, dst f32");
+    const bool kv_q80 = (k->type == MI355Q_TYPE_Q8_0 && v->type == MI355Q_TYPE_Q8_0) || (k->type == MI355Q_TYPE_Q4_0 && v->type == MI355Q_TYPE_Q4_0);     // a quantized cache
+    const int  kv_bb = k->type == MI355Q_TYPE_Q4_0 ? 18 : 34;
+    if (q->type != 0 || !((k->type == 1 && v->type == 1) || kv_q80) || dst->type != 0 || (mask && mask->type != 1)) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q f32, k / v both f16, both q8_0 or both q4_0, mask f16, dst f32");
     const int64_t DK = k->ne[0], DV = v->ne[0], n_kv = k->ne[1], N = q->ne[1], n_head = q->ne[2], nb3 = q->ne[3];
     if (q->ne[0] != DK || v->ne[1] != n_kv || k->ne[2] <= 0 || v->ne[2] <= 0 || n_head % k->ne[2] || n_head % v->ne[2] || k->ne[3] <= 0 || v->ne[3] <= 0 ||
         nb3 % k->ne[3] || nb3 % v->ne[3] || dst->ne[0] != DV || dst->ne[1] != n_head || dst->ne[2] != N || dst->ne[3] != nb3)
         OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: q [DK, N, H, B], k [DK, n_kv, Hk, Bk], v [DV, n_kv, Hv, Bv], dst [DV, H, N, B]");
-    if (q->nb[0] != 4 || k->nb[0] != (kv_q80 ? 34 : 2) || v->nb[0] != (kv_q80 ? 34 : 2) || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: innermost dimensions must be contiguous");
+    if (q->nb[0] != 4 || k->nb[0] != (kv_q80 ? kv_bb : 2) || v->nb[0] != (kv_q80 ? kv_bb : 2) || dst->nb[0] != 4) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: innermost dimensions must be contiguous");
     if (mask && (mask->ne[0] < n_kv || mask->ne[1] < N || mask->nb[0] != 2)) OPS_FAIL(MI355Q_ERR_SHAPE, "op_flash_attn_ext: mask f16 [>= n_kv, >= N]");
     if (DK > 256 || DV > 256 || DK < 1 || DV < 1) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: head sizes up to 256");
     if (n_kv > 36864) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: n_kv > 36864 (one row of scores lives in LDS)");
@@ -1213,12 +1265,17 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
         if (lds > 48 * 1024) {
             int dev = 0; (void) hipGetDevice(&dev); dev = dev >= 0 && dev < 64 ? dev : 0;
             if (!attr_q80[dev]) {
-                if (hipFuncSetAttribute((const void *) k_flash_attn_ext_q80, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "op_flash_attn_ext: LDS attribute");
+                if (hipFuncSetAttribute((const void *) k_flash_attn_ext_q80<MI355Q_TYPE_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void *) k_flash_attn_ext_q80<MI355Q_TYPE_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) OPS_FAIL(MI355Q_ERR_HIP, "op_flash_attn_ext: LDS attribute");
                 attr_q80[dev] = true;
             }
         }
-        hipLaunchKernelGGL(k_flash_attn_ext_q80, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
-                           to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2);
+        if (k->type == MI355Q_TYPE_Q8_0)
+            hipLaunchKernelGGL(k_flash_attn_ext_q80<MI355Q_TYPE_Q8_0>, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
+                               to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2);
+        else
+            hipLaunchKernelGGL(k_flash_attn_ext_q80<MI355Q_TYPE_Q4_0>, dim3((unsigned) N, (unsigned) n_head, (unsigned) nb3), dim3(FA_THREADS), lds, (hipStream_t) stream,
+                               to_d(q), to_d(k), to_d(v), mask ? to_d(mask) : to_d(q), mask ? 1 : 0, to_d(dst), scale, max_bias, logit_softcap, m0, m1, n_head_log2);
         OPS_LAUNCHED();
     }
     // Many query rows (prefill) and scratch for the scores: the three steps of the definition on the matrix-core kernels -- scores = K q

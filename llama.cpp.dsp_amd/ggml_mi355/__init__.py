@@ -414,13 +414,15 @@ def _td(t) -> _Tensor:
     return d
 
 
-def _td_q8_0(t) -> _Tensor:
-    """uint8 torch tensor holding contiguous block_q8_0 rows, shape [..., n / 32 * 34] (<= 4 dims) -> mi355q_tensor of type Q8_0 with ne[0] = n."""
+def _td_q8_0(t, kv: str = "q8_0") -> _Tensor:
+    """uint8 torch tensor holding contiguous block_q8_0 (34-byte) or block_q4_0 (18-byte) rows, shape [..., n / 32 * bb] (<= 4 dims) -> mi355q_tensor of
+    that type with ne[0] = n."""
     torch = _torch()
-    assert t.dtype == torch.uint8 and t.is_contiguous() and 1 <= t.dim() <= 4 and t.shape[-1] % 34 == 0
+    bb, code = (34, 8) if kv == "q8_0" else (18, 2)
+    assert t.dtype == torch.uint8 and t.is_contiguous() and 1 <= t.dim() <= 4 and t.shape[-1] % bb == 0
     shape = list(t.shape)[::-1] + [1] * (4 - t.dim())
-    d = _Tensor(); d.data = t.data_ptr(); d.type = 8
-    d.ne[0] = shape[0] // 34 * 32; d.nb[0] = 34
+    d = _Tensor(); d.data = t.data_ptr(); d.type = code
+    d.ne[0] = shape[0] // bb * 32; d.nb[0] = bb
     d.nb[1] = shape[0]
     for i in range(1, 4):
         d.ne[i] = shape[i]
@@ -471,25 +473,25 @@ def op_unary_mul(uop: int, a, b):
     return out
 
 
-def op_flash_attn_ext(q, k, v, mask, scale: float, max_bias: float = 0.0, logit_softcap: float = 0.0, split: bool = True):
+def op_flash_attn_ext(q, k, v, mask, scale: float, max_bias: float = 0.0, logit_softcap: float = 0.0, split: bool = True, kv: str = "q8_0"):
     """GGML_OP_FLASH_ATTN_EXT: q f32 [B, H, N, DK] (torch order), k f16 [Bk, Hk, n_kv, DK], v f16 [Bv, Hv, n_kv, DV], mask f16 [>= N, >= n_kv]
     or None -> f32 [B, N, H, DV]."""
     torch = _torch()
     out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), dtype=torch.float32, device=q.device)
     ws, wsb = (_workspace(torch, int(lib().mi355q_op_flash_attn_ext_workspace(v.shape[3], q.shape[2], q.shape[1], q.shape[0], k.shape[2])), q.device)
                if split else (None, 0))
-    tdkv = _td_q8_0 if k.dtype == torch.uint8 else _td                  # (uint8: block_q8_0 rows, a quantized cache)
+    tdkv = (lambda t: _td_q8_0(t, kv)) if k.dtype == torch.uint8 else _td      # (uint8: block_q8_0 / block_q4_0 rows, a quantized cache)
     if k.dtype == torch.uint8:
-        out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3] // 34 * 32), dtype=torch.float32, device=q.device)
+        out = torch.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3] // (34 if kv == "q8_0" else 18) * 32), dtype=torch.float32, device=q.device)
     _check(lib().mi355q_op_flash_attn_ext(C.byref(_td(q)), C.byref(tdkv(k)), C.byref(tdkv(v)), C.byref(_td(mask)) if mask is not None else None,
                                           C.byref(_td(out)), scale, max_bias, logit_softcap, ws.data_ptr() if ws is not None else None, wsb,
                                           _stream(torch)), "op_flash_attn_ext")
     return out
 
 
-def op_cpy(a, out):
-    """GGML_OP_CPY; a uint8 `out` of shape [..., n / 32 * 34] is a Q8_0 destination (quantized KV cache rows)."""
-    td_out = _td_q8_0(out) if out.dtype == _torch().uint8 else _td(out)
+def op_cpy(a, out, kv: str = "q8_0"):
+    """GGML_OP_CPY; a uint8 `out` of shape [..., n / 32 * 34] (kv "q8_0") or [..., n / 32 * 18] ("q4_0") is a quantized destination (KV cache rows)."""
+    td_out = _td_q8_0(out, kv) if out.dtype == _torch().uint8 else _td(out)
     _check(lib().mi355q_op_cpy(C.byref(_td(a)), C.byref(td_out), _stream(_torch())), "op_cpy")
     return out
 

@@ -248,16 +248,17 @@ class Reference:
             raise RuntimeError(f"ref_flash_attn_ext failed: {rc}")
         return out
 
-    def flash_attn_ext_q8_0(self, q, k, v, mask, scale: float, max_bias: float = 0.0, softcap: float = 0.0, n_threads: int = 1):
+    def flash_attn_ext_q8_0(self, q, k, v, mask, scale: float, max_bias: float = 0.0, softcap: float = 0.0, n_threads: int = 1, kv_type: int = 8):
         """FLASH_ATTN_EXT on a Q8_0 K / V cache on the reference CPU backend: k / v (f32) are quantized by the reference quantizer
         (ggml_quantize_chunk).  Returns (out [B, N, H, DV] f32, k blocks uint8 [B, Hk, n_kv, DK/32*34], v blocks likewise)."""
         q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
         ne = lambda x: np.asarray(list(x.shape)[::-1], np.int64)
         m = np.ascontiguousarray(mask, np.float32) if mask is not None else None
         out = np.empty((q.shape[0], q.shape[2], q.shape[1], v.shape[3]), np.float32)
-        kb = np.empty(k.shape[:-1] + (k.shape[-1] // 32 * 34,), np.uint8); vb = np.empty(v.shape[:-1] + (v.shape[-1] // 32 * 34,), np.uint8)
+        bb = 34 if kv_type == Q8_0 else 18                               # (Q8_0 or Q4_0 blocks)
+        kb = np.empty(k.shape[:-1] + (k.shape[-1] // 32 * bb,), np.uint8); vb = np.empty(v.shape[:-1] + (v.shape[-1] // 32 * bb,), np.uint8)
         rc = self.lib.ref_flash_attn_ext_t(_ptr(q), _ptr(ne(q)), _ptr(k), _ptr(ne(k)), _ptr(v), _ptr(ne(v)), _ptr(m) if m is not None else None,
-                                           m.shape[0] if m is not None else 0, scale, max_bias, softcap, Q8_0, _ptr(out), _ptr(kb), _ptr(vb), n_threads)
+                                           m.shape[0] if m is not None else 0, scale, max_bias, softcap, kv_type, _ptr(out), _ptr(kb), _ptr(vb), n_threads)
         if rc != 0:
             raise RuntimeError(f"ref_flash_attn_ext_t failed: {rc}")
         return out, kb, vb

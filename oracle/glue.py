@@ -232,19 +232,25 @@ def vec_dot_q8_0_q8_0_simd(kd: np.ndarray, kq: np.ndarray, qd: np.ndarray, qq: n
 
 
 def flash_attn_ext_q8_0(q: np.ndarray, k_blocks: np.ndarray, v_blocks: np.ndarray, mask: np.ndarray | None, scale: float, max_bias: float = 0.0,
-                        logit_softcap: float = 0.0) -> np.ndarray:
+                        logit_softcap: float = 0.0, kv: str = "q8_0") -> np.ndarray:
     """FLASH_ATTN_EXT on a Q8_0 K / V cache (ops.cpp:6686-6905 with k->type = v->type = Q8_0).  q: [B, H, N, DK] f32; k_blocks / v_blocks: the cache rows
     as stored, uint8 [B, Hk, n_kv, DK/32*34] (block_q8_0: f16 d, 32 int8).  The CPU quantizes q to Q8_0 (the K type's vec_dot_type; SIMD quantizer),
     takes the scores with ggml_vec_dot_q8_0_q8_0, walks the positions in order with a running maximum, and keeps V.P in an F32 accumulator: V is
-    dequantized (q * d), the accumulator rescaled by an f32 multiply when the maximum grows and updated with an f32 fma per position."""
+    dequantized (q * d), the accumulator rescaled by an f32 multiply when the maximum grows and updated with an f32 fma per position.
+    kv = "q4_0": the same on a Q4_0 cache (block_q4_0: f16 d, 16 bytes of nibbles, low nibbles = elements 0..15, value = nibble - 8; the K dot is
+    ggml_vec_dot_q4_0_q8_0, whose AVX2 form has the lane structure of the Q8_0 one after bytes_from_nibbles_32)."""
     q = np.asarray(q, f32)
     B, H, N, DK = q.shape
     Hk, n_kv = k_blocks.shape[1], k_blocks.shape[2]
+    bb = 34 if kv == "q8_0" else 18
     def unpack(blk):
-        nbk = blk.shape[-1] // 34
-        b = np.ascontiguousarray(blk).reshape(blk.shape[:-1] + (nbk, 34))
+        nbk = blk.shape[-1] // bb
+        b = np.ascontiguousarray(blk).reshape(blk.shape[:-1] + (nbk, bb))
         d = np.ascontiguousarray(b[..., :2]).view(np.float16)[..., 0]
-        return d, np.ascontiguousarray(b[..., 2:]).view(np.int8)
+        if kv == "q8_0":
+            return d, np.ascontiguousarray(b[..., 2:]).view(np.int8)
+        qs = b[..., 2:].astype(np.int16)
+        return d, np.concatenate([(qs & 15) - 8, (qs >> 4) - 8], axis=-1).astype(np.int8)       # elements 0..15 | 16..31
     kd, kq = unpack(k_blocks); vd, vq = unpack(v_blocks)
     DV = vq.shape[-2] * 32
     n_head_log2 = 1 << int(np.floor(np.log2(H)))

@@ -331,26 +331,47 @@ def test_cpy_f32_to_q8_0_is_the_reference_quantizer(G, torch):
     assert np.array_equal(out.cpu().numpy().reshape(-1), np.ascontiguousarray(want).view(np.uint8).reshape(-1))
 
 
+@pytest.mark.parametrize("kv", ["q8_0", "q4_0"])
 @pytest.mark.parametrize("cfg", [(8, 2, 1, 128, 256, 201, 0.0), (4, 4, 3, 64, 96, 60, 0.0), (8, 8, 2, 128, 64, 55, 8.0), (2, 1, 1, 256, 40, 30, 0.0)], ids=str)
-def test_flash_attn_ext_q8_0_cache(G, torch, cfg):
-    """FLASH_ATTN_EXT on a Q8_0 K / V cache (-ctk q8_0 -ctv q8_0) against oracle.glue.flash_attn_ext_q8_0, which is bit-exact with the reference CPU
-    backend (tests/test_oracle_glue.py): q quantized to Q8_0, ggml_vec_dot_q8_0_q8_0's lane order, the online softmax in order, an F32 accumulator.
-    Plain cases: every output bit; with ALiBi (device powf) within the last place.  The cache rows are written by the device's own CPY."""
+def test_flash_attn_ext_q8_0_cache(G, torch, cfg, kv):
+    """FLASH_ATTN_EXT on a Q8_0 / Q4_0 K / V cache (-ctk q8_0 -ctv q8_0 and the q4_0 forms) against oracle.glue.flash_attn_ext_q8_0, which is bit-exact with
+    the reference CPU backend (tests/test_oracle_glue.py): q quantized to Q8_0, ggml_vec_dot_q8_0_q8_0's / _q4_0_q8_0's lane order, the online softmax in
+    order, an F32 accumulator.  Plain cases: every output bit; with ALiBi (device powf) within the last place.  The cache rows are written by the device's
+    own CPY."""
     H, Hk, N, DK, n_kv, first_masked, max_bias = cfg
+    bb = 34 if kv == "q8_0" else 18
     rng = np.random.default_rng(sum(cfg[:6]))
     q = rng.standard_normal((1, H, N, DK)).astype(np.float32)
     kf = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float32); vf = rng.standard_normal((1, Hk, n_kv, DK)).astype(np.float32)
-    kb = torch.zeros((1, Hk, n_kv, DK // 32 * 34), dtype=torch.uint8, device="cuda"); vb = torch.zeros_like(kb)
-    G.op_cpy(dev(torch, kf), kb); G.op_cpy(dev(torch, vf), vb)
+    kb = torch.zeros((1, Hk, n_kv, DK // 32 * bb), dtype=torch.uint8, device="cuda"); vb = torch.zeros_like(kb)
+    G.op_cpy(dev(torch, kf), kb, kv); G.op_cpy(dev(torch, vf), vb, kv)
     mask = np.zeros((64, n_kv), np.float16)
     for t in range(N):
         mask[t, first_masked + t:] = -np.inf
     if max_bias > 0:
         mask[:N] += (rng.standard_normal((N, n_kv)) * 0.1).astype(np.float16)
     scale = float(np.float32(1.0 / np.sqrt(DK)))
-    y = G.op_flash_attn_ext(dev(torch, q), kb, vb, dev(torch, mask), scale, max_bias, 0.0).cpu().numpy()
-    want = glue.flash_attn_ext_q8_0(q, kb.cpu().numpy(), vb.cpu().numpy(), mask, scale, max_bias, 0.0)
+    y = G.op_flash_attn_ext(dev(torch, q), kb, vb, dev(torch, mask), scale, max_bias, 0.0, kv=kv).cpu().numpy()
+    want = glue.flash_attn_ext_q8_0(q, kb.cpu().numpy(), vb.cpu().numpy(), mask, scale, max_bias, 0.0, kv=kv)
     assert np.isfinite(y).all()
     d = np.abs(y.astype(np.float64) - want); top = np.abs(want).max()
     differ = (y.view(np.uint32) != want.view(np.uint32)).mean()
-    assert d.max() <= 1e-5 * top and (differ == 0.0 if max_bias == 0.0 else True), (cfg, d.max() / top, differ)
+    assert d.max() <= 1e-5 * top and (differ == 0.0 if max_bias == 0.0 else True), (cfg, kv, d.max() / top, differ)
+
+
+def test_cpy_f32_to_q4_0_is_the_reference_quantizer(G, torch):
+    """CPY f32 -> Q4_0: block for block the bytes of quantize_row_q4_0_ref (the reference's ggml_quantize_chunk through oracle/_ref): the FIRST element
+    of largest magnitude sets the scale (ties included), all-zero blocks, a strided source."""
+    if not oracle.ref_available("scalar"):
+        pytest.skip("oracle/_ref/scalar not built")
+    ref = oracle.Reference("scalar")
+    rng = np.random.default_rng(32)
+    x = (rng.standard_normal((3, 5, 256)) * rng.uniform(0.01, 20.0, (3, 5, 1))).astype(np.float32)
+    x[1, 2, 32:64] = 0.0
+    x[0, 0, 3] = 7.25; x[0, 0, 17] = -7.25; x[0, 0, :32] = np.clip(x[0, 0, :32], -7.25, 7.25)       # a tie of magnitudes: the first (positive) one decides the sign of d
+    x[0, 1, 40] = -9.5; x[0, 1, 33] = 9.5; x[0, 1, 32:64] = np.clip(x[0, 1, 32:64], -9.5, 9.5)       # the first one is the later lane's? no: element 33 comes first
+    big = dev(torch, np.concatenate([x, np.zeros_like(x)], axis=-1))
+    out = torch.zeros((3, 5, 256 // 32 * 18), dtype=torch.uint8, device="cuda")
+    G.op_cpy(big[..., :256], out, "q4_0")
+    want = ref.quantize(oracle.Q4_0, x.reshape(-1, 256))
+    assert np.array_equal(out.cpu().numpy().reshape(-1), np.ascontiguousarray(want).view(np.uint8).reshape(-1))

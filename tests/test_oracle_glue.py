@@ -94,9 +94,10 @@ for t in range(N):
 mask[:, 5] = -np.inf                                             # a hole in the middle: skipped, not weighted by zero
 if max_bias > 0:
     mask[:N] += (rng.standard_normal((N, n_kv)) * 0.1).astype(np.float16)
-if len(sys.argv) > 4 and sys.argv[4] == "q8_0":                  # the same on a Q8_0 K / V cache
-    want, kb, vb = r.flash_attn_ext_q8_0(q, k.astype(np.float32), v.astype(np.float32), mask, 1.0 / np.sqrt(DK), max_bias, softcap)
-    got = glue.flash_attn_ext_q8_0(q, kb, vb, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
+if len(sys.argv) > 4 and sys.argv[4] in ("q8_0", "q4_0"):        # the same on a Q8_0 / Q4_0 K / V cache
+    want, kb, vb = r.flash_attn_ext_q8_0(q, k.astype(np.float32), v.astype(np.float32), mask, 1.0 / np.sqrt(DK), max_bias, softcap,
+                                         kv_type=oracle.Q8_0 if sys.argv[4] == "q8_0" else oracle.Q4_0)
+    got = glue.flash_attn_ext_q8_0(q, kb, vb, mask, 1.0 / np.sqrt(DK), max_bias, softcap, kv=sys.argv[4])
 else:
     got = glue.flash_attn_ext(q, k, v, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
     want = r.flash_attn_ext(q, k, v, mask, 1.0 / np.sqrt(DK), max_bias, softcap)
@@ -129,16 +130,17 @@ def test_flash_attn_ext_bitexact(variant, cfg):
         assert st["max_rel"] <= 2e-3 and st["flips"] <= 0.02, st
 
 
+@pytest.mark.parametrize("kv", ["q8_0", "q4_0"])
 @pytest.mark.parametrize("cfg", [(8, 2, 1, 128, 96, 0.0, 0.0), (4, 4, 3, 64, 40, 0.0, 0.0), (8, 2, 2, 128, 256, 4.0, 0.0), (4, 1, 1, 96, 64, 0.0, 10.0)], ids=str)
-def test_flash_attn_ext_q8_0_cache_bitexact(cfg):
-    """FLASH_ATTN_EXT on a Q8_0 K / V cache: q quantized to Q8_0 by the SIMD quantizer, ggml_vec_dot_q8_0_q8_0's AVX2 lane order, the online softmax in
+def test_flash_attn_ext_q8_0_cache_bitexact(cfg, kv):
+    """FLASH_ATTN_EXT on a Q8_0 / Q4_0 K / V cache: q quantized to Q8_0 by the SIMD quantizer, ggml_vec_dot_q8_0_q8_0's AVX2 lane order, the online softmax in
     order, V dequantized into an F32 accumulator -- the restatement against the reference's AVX2 build, bit for bit (own process: see above)."""
     import json, subprocess, sys
     from pathlib import Path
     if not oracle.ref_available("avx2"):
         pytest.skip("oracle/_ref/avx2 not built")
     root = str(Path(__file__).resolve().parents[1])
-    pr = subprocess.run([sys.executable, "-c", _FLASH_PIN_SCRIPT, root, "avx2", json.dumps(list(cfg)), "q8_0"], capture_output=True, text=True, timeout=300)
+    pr = subprocess.run([sys.executable, "-c", _FLASH_PIN_SCRIPT, root, "avx2", json.dumps(list(cfg)), kv], capture_output=True, text=True, timeout=300)
     if "ref_flash_attn_ext_t" in pr.stderr and "AttributeError" in pr.stderr:
         pytest.skip("refshim without ref_flash_attn_ext_t (stale oracle/_ref)")
     assert pr.returncode == 0, pr.stderr[-1500:]
