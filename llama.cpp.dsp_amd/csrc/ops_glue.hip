@@ -791,6 +791,23 @@ __global__ void __launch_bounds__(FA_THREADS) k_flash_attn_ext_q80(const TensorD
     }
 }
 
+// a quantized cache for the prefill path: K / V rows of all (kv head, batch) pairs -> F16 [B][H][n_kv][D] in scratch (value = q * d, rounded to f16), so that the
+// matrix-core kernels of the f16 path can take them.  One thread per element pair.
+template <int KVT>
+__global__ void __launch_bounds__(256) k_dequant_cache_f16(const TensorD t, __half * __restrict__ out) {
+    constexpr int BB = KVT == MI355Q_TYPE_Q8_0 ? 34 : 18;
+    const int64_t D = t.ne[0], n_kv = t.ne[1], H = t.ne[2], B = t.ne[3], n = D * n_kv * H * B;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t e = i % D, r = i / D, j = r % n_kv, r2 = r / n_kv, h = r2 % H, b = r2 / H;
+        const char * blk = t.data + j * t.nb[1] + h * t.nb[2] + b * t.nb[3] + BB * (e >> 5);
+        const int ee = (int) (e & 31);
+        int qv;
+        if constexpr (KVT == MI355Q_TYPE_Q8_0) qv = (int) *(const int8_t *) (blk + 2 + ee);
+        else { const int byte = (int) *(const uint8_t *) (blk + 2 + (ee & 15)); qv = ((ee < 16 ? byte : byte >> 4) & 15) - 8; }
+        out[i] = __float2half_rn(__fmul_rn((float) qv, __half2float(*(const __half *) blk)));
+    }
+}
+
 // merge the pieces of a split row: out = sum_s e^(m_s - M) o_s / sum_s e^(m_s - M) l_s
 __global__ void __launch_bounds__(256) k_flash_attn_combine(const float * __restrict__ part, int n_split, int64_t DV, int64_t N, const TensorD d) {
     const int64_t t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -1232,7 +1249,7 @@ int mi355q_op_mul_mat_f(const mi355q_tensor * a, const mi355q_tensor * b, const 
 }
 
 size_t mi355q_op_flash_attn_ext_workspace(int64_t dv, int64_t n_q, int64_t n_head, int64_t n_batch, int64_t n_kv) {
-    if (n_q >= 16) return (size_t) (n_q * n_kv * n_head * n_batch * 4);     // prefill: the scores of the batch
+    if (n_q >= 16) return (size_t) (n_q * n_kv * n_head * n_batch * 4) + 256 + (size_t) (4 * n_kv * n_head * n_batch * (dv > 256 ? dv : 256));     // prefill: the scores of the batch (+ an f16 copy of a quantized K / V cache, at most n_head kv heads of 256)
     if (n_q * n_head * n_batch > 256) return 0;
     return (size_t) (8 * n_q * n_head * n_batch * (dv + 2) * 4);            // up to 8 pieces per row
 }
@@ -1258,6 +1275,29 @@ int mi355q_op_flash_attn_ext(const mi355q_tensor * q, const mi355q_tensor * k, c
     if (logit_softcap != 0.0f) scale /= logit_softcap;                          // ops.cpp:6757-6759
     uint32_t n_head_log2 = 1; while (2 * n_head_log2 <= (uint32_t) n_head) n_head_log2 *= 2;
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    mi355q_tensor k16, v16;                                   // (a quantized cache under a prefill batch: its f16 copy)
+    if (kv_q80 && N >= 16 && logit_softcap == 0.0f && workspace && DK % 32 == 0 && DV % 32 == 0) {
+        // Many query rows: one workgroup per row re-streams (and re-decodes) the cache for every row.  The cache is decoded ONCE into scratch as f16 and the
+        // matrix-core path below takes it (q in f16 against the dequantized K instead of the CPU's Q8_0-quantized q: ~1e-3 of a score, NMSE 1e-6 of the
+        // output; the decode path, N < 16, keeps the CPU's exact arithmetic).
+        const size_t sc_bytes = ((size_t) N * (size_t) n_kv * (size_t) n_head * (size_t) nb3 * 4 + 255) & ~(size_t) 255;
+        const size_t kb16 = (size_t) DK * n_kv * k->ne[2] * k->ne[3] * 2, vb16 = (size_t) DV * n_kv * v->ne[2] * v->ne[3] * 2;
+        if (workspace_bytes >= sc_bytes + ((kb16 + 255) & ~(size_t) 255) + vb16) {
+            __half * kp = (__half *) ((char *) workspace + sc_bytes), * vp = (__half *) ((char *) kp + ((kb16 + 255) & ~(size_t) 255));
+            if (k->type == MI355Q_TYPE_Q8_0) {
+                hipLaunchKernelGGL(k_dequant_cache_f16<MI355Q_TYPE_Q8_0>, dim3(grid_for((int64_t) (kb16 / 2))), dim3(256), 0, (hipStream_t) stream, to_d(k), kp);
+                hipLaunchKernelGGL(k_dequant_cache_f16<MI355Q_TYPE_Q8_0>, dim3(grid_for((int64_t) (vb16 / 2))), dim3(256), 0, (hipStream_t) stream, to_d(v), vp);
+            } else {
+                hipLaunchKernelGGL(k_dequant_cache_f16<MI355Q_TYPE_Q4_0>, dim3(grid_for((int64_t) (kb16 / 2))), dim3(256), 0, (hipStream_t) stream, to_d(k), kp);
+                hipLaunchKernelGGL(k_dequant_cache_f16<MI355Q_TYPE_Q4_0>, dim3(grid_for((int64_t) (vb16 / 2))), dim3(256), 0, (hipStream_t) stream, to_d(v), vp);
+            }
+            auto as16 = [](const mi355q_tensor * t, __half * p, mi355q_tensor & o) {
+                o = *t; o.data = p; o.type = 1; o.nb[0] = 2; o.nb[1] = 2 * t->ne[0]; o.nb[2] = o.nb[1] * t->ne[1]; o.nb[3] = o.nb[2] * t->ne[2];
+            };
+            as16(k, kp, k16); as16(v, vp, v16);
+            return mi355q_op_flash_attn_ext(q, &k16, &v16, mask, dst, logit_softcap != 0.0f ? scale * logit_softcap : scale, max_bias, logit_softcap, workspace, sc_bytes, stream);
+        }
+    }
     if (kv_q80) {                                            // a quantized cache: one workgroup per row with the CPU's arithmetic (k_flash_attn_ext_q80)
         if (DK % 32 || DV % 32 || n_kv > 8192) OPS_FAIL(MI355Q_ERR_UNSUPPORTED, "op_flash_attn_ext: q8_0 cache needs head sizes of whole 32-blocks and n_kv <= 8192");
         const size_t lds = (size_t) (2 * n_kv + DK / 32 + DK / 4) * 4;
