@@ -1340,6 +1340,9 @@ k_plan(const PlanStage * stages_g, int n_stages, unsigned * sync, int even, unsi
         }
         c.stage = (int) (st - stages);
         s += grp > 1 ? grp - 1 : 0;
+        // (a GEMV stage may leave workgroups out: the one behind an attention stage is not given to the workgroups that ran the attention -- they arrive last,
+        //  and with rows of their own the whole stage would end a descriptor + prime + memory latency later)
+        if (grp == 1 && ((int) blockIdx.x < st->wg_base || (int) blockIdx.x >= st->wg_base + st->wg_count)) continue;
         c.next_desc = s + 1 < n_stages ? (const uint8_t *) (stages_g + s + 1) : nullptr;
         c.next_desc2 = s + 2 < n_stages ? (const uint8_t *) (stages_g + s + 2) : nullptr;
         c.next_attn = (const uint8_t *) st->next_attn;
@@ -1604,6 +1607,21 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
         }
     }
     if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
+    {   // the stage that consumes an attention output (wo) runs on the workgroups that did NOT run the attention (MI355Q_PLAN_WO_SKIP=0: on all)
+        static const bool no_skip = getenv("MI355Q_PLAN_WO_SKIP") && atoi(getenv("MI355Q_PLAN_WO_SKIP")) == 0;
+        for (size_t si = 1; si < v.size() && !no_skip; ++si) {
+            PlanStage & p = v[si];
+            if (p.kind != PLAN_K_GEMV || p.group != 1 || p.wg_count != n_cu || (p.flags & PLAN_F_PAIRED) || v[si - 1].kind == PLAN_K_GEMV) continue;
+            size_t ai = si - 1; while (ai > 0 && v[ai].kind == PLAN_K_COMBINE) --ai;
+            if (v[ai].kind != PLAN_K_ATTN) continue;
+            const AttnStage & A = va[attn_of[ai]];
+            const int n_attn = A.n_head * A.n_split;
+            if (n_attn > n_cu / 2) continue;
+            p.wg_base = n_attn; p.wg_count = n_cu - n_attn;
+            p.rows_per_wg = (p.total_rows + p.wg_count - 1) / p.wg_count; if (p.rows_per_wg < 1) p.rows_per_wg = 1;
+            p.pub_wg = p.wg_base + (int) (si % (size_t) p.wg_count);
+        }
+    }
     {   // attention stages whose K / V window (2 x per x hd f16) fits beside everything else run from LDS (plan_attn_lds)
         const size_t fixed = lds_max + 64 + 8 * GEMV_WAVES + 1024, cap = 160 * 1024 - 64;
         const char * e = getenv("MI355Q_PLAN_KV_LDS"), * e2 = getenv("MI355Q_PLAN_FA_EXACT");
