@@ -385,6 +385,47 @@ def test_mixed_type_stage_runs_as_a_group(G, torch, groups):
     plan.close()
 
 
+@pytest.mark.parametrize("n_kv", [96, 600], ids=["one_split", "three_splits_and_merge"])
+def test_stage_behind_attention_skips_the_attention_workgroups(G, torch, n_kv):
+    """wq|wk|wv -> ATTN (-> COMBINE) -> wo -> a following stage: `wo` is dealt to the workgroups that did not run the attention (they arrive last); with
+    MI355Q_PLAN_WO_SKIP=0 every workgroup takes part.  Both forms give the same bits -- rows do not care which wave computes them -- and equal the node path's
+    wo(attention output)."""
+    import os
+    n_head, n_head_kv, hd, pos = 32, 8, 128, 57
+    rng = np.random.default_rng(101 + n_kv)
+    E = 2048
+    n_q, n_k, n_ctx = n_head * hd, n_head_kv * hd, n_kv + 32
+    wq, wk, wv = W(G, oracle.Q4_K, n_q, E, rng), W(G, oracle.Q4_K, n_k, E, rng), W(G, oracle.Q6_K, n_k, E, rng)
+    wo, wn = W(G, oracle.Q4_K, E, n_q, rng), W(G, oracle.Q4_K, 512, E, rng)
+    x = dev(torch, rng.standard_normal((1, E)).astype(np.float32))
+    kc_h = rng.standard_normal((n_ctx, n_k)).astype(np.float16); vc_h = rng.standard_normal((n_k, n_ctx)).astype(np.float16)
+    mask_h = np.full(n_kv, -np.inf, np.float32); mask_h[:pos + 1] = 0.0
+    posd = dev(torch, np.array([pos], np.int32))
+    res = {}
+    for skip in ("1", "0"):
+        kc, vc = dev(torch, kc_h), dev(torch, vc_h)
+        z = lambda n: torch.zeros((1, n), dtype=torch.float32, device="cuda")
+        q, k, v, att, o, nxt = z(n_q), z(n_k), z(n_k), z(n_q), z(E), z(512)
+        dst = torch.tensor([kc.data_ptr() + pos * n_k * 2, vc.data_ptr() + pos * 2], dtype=torch.int64, device="cuda")
+        attn = dict(q=q, k=k, v=v, pos=posd, rope=dict(n_dims=hd, mode=0, n_ctx_orig=8192, freq_base=500000.0), k_cache=kc, v_cache=vc,
+                    k_nb_pos=n_k * 2, k_nb_head=hd * 2, v_nb_pos=2, v_nb_dim=n_ctx * 2, v_nb_head=hd * n_ctx * 2, k_dst=dst[0:1], v_dst=dst[1:2], v_dst_nb=n_ctx * 2,
+                    mask=dev(torch, mask_h), n_head=n_head, n_head_kv=n_head_kv, head_dim=hd, n_kv=n_kv, scale=1.0 / np.sqrt(hd), out=att)
+        os.environ["MI355Q_PLAN_WO_SKIP"] = skip
+        try:
+            plan = G.Plan([dict(ws=[wq, wk, wv], ys=[q, k, v], x=x), dict(attn=attn), dict(ws=[wo], ys=[o], x=att), dict(ws=[wn], ys=[nxt], x=o)])
+        finally:
+            del os.environ["MI355Q_PLAN_WO_SKIP"]
+        for _ in range(2):
+            plan.run()
+        torch.cuda.synchronize()
+        assert plan.status() == 0
+        res[skip] = (att.cpu().numpy(), o.cpu().numpy(), nxt.cpu().numpy())
+        assert np.array_equal(bits(o), bits(G.mul_mat(wo, att))) and np.array_equal(bits(nxt), bits(G.mul_mat(wn, o)))
+        plan.close()
+    for a_, b_ in zip(res["1"], res["0"]):
+        assert np.array_equal(a_.view(np.uint32), b_.view(np.uint32))
+
+
 def test_plan_timeout_is_reported_not_hung(G, torch):
     """An operand that claims to come from an earlier stage but is never produced cannot be built through the API (dependencies follow
     from addresses), so the bounded poll is exercised the only way possible: a plan whose launch is healthy reports status 0 repeatedly,
