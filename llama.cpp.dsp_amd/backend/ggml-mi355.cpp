@@ -767,12 +767,15 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, stru
         for (int i = 0; i < ctx->plan_declined_n; ++i) declined = declined || ctx->plan_declined[i] == key;
         if (!e && !declined) {
             mi355_plan_entry * ne = new mi355_plan_entry();
-            if (mi355_plan_compile(ctx, cgraph, *ne)) {
+            if (ctx->plans.size() >= 4) {                          // evict the least recently used plan FIRST (its launches must have finished): its device
+                MQ_CHECK(mi355q_stream_synchronize(ctx->stream));  // block is what the new plan is built in (csrc/plan.hip keeps destroyed plans' blocks)
+                mi355q_plan_destroy(ctx->plans.back()->plan); delete ctx->plans.back(); ctx->plans.pop_back();
+            }
+            const auto t_c0 = std::chrono::steady_clock::now();
+            const bool compiled = mi355_plan_compile(ctx, cgraph, *ne);
+            if (timing) fprintf(stderr, "MI355 plan compile: %.0f us (%s)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_c0).count(), compiled ? "built" : "declined");
+            if (compiled) {
                 ne->key = key; ne->key2 = key2; ne->n_nodes = cgraph->n_nodes;
-                if (ctx->plans.size() >= 4) {                      // evict the least recently used plan (its launches must have finished)
-                    MQ_CHECK(mi355q_stream_synchronize(ctx->stream));
-                    mi355q_plan_destroy(ctx->plans.back()->plan); delete ctx->plans.back(); ctx->plans.pop_back();
-                }
                 ctx->plans.insert(ctx->plans.begin(), ne);
                 e = ne; ++ctx->n_plans_built;
             } else { delete ne; ctx->plan_declined[ctx->plan_declined_n < 8 ? ctx->plan_declined_n++ : (int) (key & 7)] = key; }

@@ -27,6 +27,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <vector>
+#include <cstring>
+#include <chrono>
+#include <mutex>
 
 #include "gemv_stream.cuh"
 
@@ -1376,6 +1379,7 @@ struct Plan {
     unsigned      set = 0;
     size_t        lds_image = 0, lds_total = 0;
     int64_t       weight_bytes = 0;
+    unsigned char * d_block = nullptr; size_t block_bytes = 0; // the one device allocation the four pointers below point into
     PlanStage *   d_stages = nullptr;
     AttnStage *   d_attn = nullptr;
     unsigned *    d_sync = nullptr;
@@ -1384,6 +1388,29 @@ struct Plan {
 };
 
 int gemv_fast_family(int type);
+
+// Device blocks of destroyed plans, kept for the next plan: a generation builds one plan per KV window (32 positions) and drops the least recently used
+// one, and hipMalloc + hipFree of the ~9 MB block (descriptors + one granule per stage output element) was most of the build's 1.6 ms.  At most
+// PLAN_POOL blocks are held (per process; the caller of destroy has synchronized the plan's stream, so a block handed on is idle).
+enum { PLAN_POOL = 4 };
+static std::mutex g_pool_mu;
+static struct { unsigned char * p; size_t bytes; int dev; } g_pool[PLAN_POOL];
+static bool plan_block_take(int dev, size_t need, unsigned char ** out, size_t * out_bytes) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < PLAN_POOL; ++i) if (g_pool[i].p && g_pool[i].dev == dev && g_pool[i].bytes >= need && g_pool[i].bytes <= 2 * need + (1u << 20) && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best < 0) return false;
+    *out = g_pool[best].p; *out_bytes = g_pool[best].bytes; g_pool[best].p = nullptr;
+    return true;
+}
+static void plan_block_give(int dev, unsigned char * p, size_t bytes) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (int i = 0; i < PLAN_POOL; ++i) if (!g_pool[i].p) { g_pool[i].p = p; g_pool[i].bytes = bytes; g_pool[i].dev = dev; return; }
+    }
+    (void) hipFree(p);
+}
 
 static const void * plan_kernel(unsigned set) {
     if ((set & ~SET_K46) == 0)  return (const void *) k_plan<SET_K46>;
@@ -1415,9 +1442,16 @@ namespace { struct OutRange { const float * p; int64_t n; size_t gran_off; unsig
 
 int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int n_stages, int flags) {
     if (!out || !stages || n_stages < 1) { mi355q_set_error("plan_create: null argument / no stages"); return MI355Q_ERR_SHAPE; }
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { mi355q_set_error("plan_create: no device"); return MI355Q_ERR_HIP; }
-    const int n_cu = prop.multiProcessorCount;
+    const auto t_create0 = std::chrono::steady_clock::now();
+    int dev = 0;
+    static int cu_of[64];                                      // (hipGetDeviceProperties fills a 1.5 KB struct through the driver: once per device, not once per plan)
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { mi355q_set_error("plan_create: no device"); return MI355Q_ERR_HIP; }
+    if (!cu_of[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { mi355q_set_error("plan_create: no device"); return MI355Q_ERR_HIP; }
+        cu_of[dev] = prop.multiProcessorCount;
+    }
+    const int n_cu = cu_of[dev];
 
     std::vector<PlanStage> v;
     std::vector<AttnStage> va;
@@ -1653,16 +1687,25 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
     const void * kern = plan_kernel(set);
     if (!kern) { delete pl; mi355q_set_error("plan_create: this mix of weight types has no kernel instantiation"); return MI355Q_ERR_UNSUPPORTED; }
     int per_cu = 0;
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+    static thread_local struct { const void * kern; size_t lds; int dev; } fits = { nullptr, 0, -1 };   // (the last answer: the next KV window's plan asks the same question)
+    if (fits.kern == kern && fits.lds >= lds_total && fits.dev == dev) per_cu = 1;
+    else if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GEMV_THREADS, lds_total) != hipSuccess || per_cu < 1) {
         delete pl; mi355q_set_error("plan_create: persistent kernel does not fit a CU"); return MI355Q_ERR_HIP;
     }
+    fits = { kern, lds_total, dev };
     pl->grid = n_cu;                                           // one workgroup per CU, all co-resident (checked again by the cooperative launch)
-    bool ok = hipMalloc((void **) &pl->d_stages, v.size() * sizeof(PlanStage)) == hipSuccess &&
-              hipMalloc((void **) &pl->d_sync, PLAN_SYNC_WORDS * sizeof(unsigned)) == hipSuccess &&
-              hipMalloc((void **) &pl->d_gran, pl->gran_count * sizeof(Granule)) == hipSuccess &&
-              (va.empty() || hipMalloc((void **) &pl->d_attn, va.size() * sizeof(AttnStage)) == hipSuccess);
+    // ONE device block -- [sync words | stage descriptors | attention descriptors | granules] -- and one upload of the first three parts: a plan is built
+    // per KV window while a generation runs (backend/decode-plan.inc), and every hipMalloc / blocking hipMemcpy of the four-block form cost the token it fell on
+    auto up256 = [](size_t n) { return (n + 255) & ~(size_t) 255; };
+    const size_t off_stages = up256(PLAN_SYNC_WORDS * sizeof(unsigned)), off_attn = off_stages + up256(v.size() * sizeof(PlanStage));
+    const size_t off_gran = off_attn + up256(va.size() * sizeof(AttnStage)), block = off_gran + pl->gran_count * sizeof(Granule);
+    const auto t_alloc0 = std::chrono::steady_clock::now();
+    bool ok = plan_block_take(dev, block, &pl->d_block, &pl->block_bytes) || (pl->block_bytes = block, hipMalloc((void **) &pl->d_block, block) == hipSuccess);
+    const auto t_alloc1 = std::chrono::steady_clock::now();
     if (ok) {
+        pl->d_sync = (unsigned *) pl->d_block; pl->d_stages = (PlanStage *) (pl->d_block + off_stages); pl->d_gran = (Granule *) (pl->d_block + off_gran);
+        pl->d_attn = va.empty() ? nullptr : (AttnStage *) (pl->d_block + off_attn);
         // patch the (offset + 1) placeholders into device pointers
         auto fix = [&](const Granule * p) { return p ? pl->d_gran + ((uintptr_t) p - 1) : nullptr; };
         auto fixs = [&](VecSrc & s) { s.gran = fix(s.gran); };
@@ -1677,16 +1720,19 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             if (v[i].kind == PLAN_K_GEMV && v[i].group > 1) nx = i + (size_t) v[i].group;
             p.next_attn = nx < v.size() && attn_of[nx] >= 0 ? pl->d_attn + attn_of[nx] : nullptr;
         }
-        ok = hipMemcpy(pl->d_stages, v.data(), v.size() * sizeof(PlanStage), hipMemcpyHostToDevice) == hipSuccess &&
-             (va.empty() || hipMemcpy(pl->d_attn, va.data(), va.size() * sizeof(AttnStage), hipMemcpyHostToDevice) == hipSuccess) &&
-             hipMemset(pl->d_sync, 0, PLAN_SYNC_WORDS * sizeof(unsigned)) == hipSuccess &&
-             hipMemset(pl->d_gran, 0, pl->gran_count * sizeof(Granule)) == hipSuccess;
+        std::vector<unsigned char> image(off_gran, 0);         // (sync words start at zero)
+        memcpy(image.data() + off_stages, v.data(), v.size() * sizeof(PlanStage));
+        if (!va.empty()) memcpy(image.data() + off_attn, va.data(), va.size() * sizeof(AttnStage));
+        ok = hipMemset(pl->d_gran, 0, pl->gran_count * sizeof(Granule)) == hipSuccess &&          // (null stream: ordered before the blocking copy below returns)
+             hipMemcpy(pl->d_block, image.data(), off_gran, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (getenv("MI355Q_PLAN_VERBOSE")) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "mi355q plan: %zu stages, device block %zu bytes; host time: descriptors %.0f us, device block %.0f us, upload + granule reset %.0f us\n",
+                v.size(), block, us(t_create0, t_alloc0), us(t_alloc0, t_alloc1), us(t_alloc1, std::chrono::steady_clock::now()));
     }
     if (!ok) {
-        if (pl->d_stages) (void) hipFree(pl->d_stages);
-        if (pl->d_sync) (void) hipFree(pl->d_sync);
-        if (pl->d_gran) (void) hipFree(pl->d_gran);
-        if (pl->d_attn) (void) hipFree(pl->d_attn);
+        if (pl->d_block) (void) hipFree(pl->d_block);
         delete pl; mi355q_set_error("plan_create: device allocation failed"); return MI355Q_ERR_HIP;
     }
     *out = (mi355q_plan *) pl;
@@ -1753,8 +1799,7 @@ int     mi355q_regs_plan_launch_stages(const mi355q_plan * plan) { return plan ?
 int mi355q_regs_plan_destroy(mi355q_plan * plan) {
     Plan * pl = (Plan *) plan;
     if (!pl) return MI355Q_OK;
-    (void) hipFree(pl->d_stages); (void) hipFree(pl->d_sync); (void) hipFree(pl->d_gran);
-    if (pl->d_attn) (void) hipFree(pl->d_attn);
+    plan_block_give(pl->device, pl->d_block, pl->block_bytes);
     delete pl;
     return MI355Q_OK;
 }
