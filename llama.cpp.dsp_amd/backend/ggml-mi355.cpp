@@ -462,11 +462,13 @@ static void mi355_glue_op(mi355_backend_ctx * ctx, struct ggml_tensor * dst, int
 
 // everything a captured launch / a decode plan depends on, EXCEPT the destination pointer of CPY nodes (read from dest_table on the device)
 static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph, uint64_t * second) {
-    uint64_t h = 1469598103934665603ull, h2 = 0x2545F4914F6CDD1Dull;
+    // four independent lanes per hash, fed round-robin and folded at the end: one chain of dependent multiplies (2 per word, ~14k words) was 16 us per token
+    uint64_t hl[4] = { 1469598103934665603ull, 0x9AE16A3B2F90404Full, 0xC3A5C85C97CB3127ull, 0xB492B66FBE98F273ull }, h2l[4] = { 0x2545F4914F6CDD1Dull, 0x1B873593CC9E2D51ull, 0x85EBCA6BC2B2AE35ull, 0x27D4EB2F165667C5ull };
+    unsigned lane = 0;
     // A token's graph is ~1000 nodes and this runs on every graph_compute: per node only what a launch can depend on is mixed in, a 64-bit word
     // at a time -- the node's op, parameters, type, shape, strides and address, and per operand its address, type and shape (an operand's strides
     // are those of its own node, or of a leaf whose address and shape fix them).
-    auto mix64 = [&](uint64_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h2 = (h2 + w) * 0xD6E8FEB86659FD93ull; h2 ^= h2 >> 32; };
+    auto mix64 = [&](uint64_t w) { uint64_t & h = hl[lane & 3], & h2 = h2l[lane & 3]; ++lane; h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h2 = (h2 + w) * 0xD6E8FEB86659FD93ull; h2 ^= h2 >> 32; };
     auto mix = [&](const void * p, size_t n) {
         const uint8_t * b = (const uint8_t *) p;
         for (; n >= 8; n -= 8, b += 8) { uint64_t w; memcpy(&w, b, 8); mix64(w); }
@@ -498,6 +500,8 @@ static uint64_t mi355_graph_key(const struct ggml_cgraph * cgraph, uint64_t * se
         }
         mix64(present);
     }
+    uint64_t h = lane, h2 = ~(uint64_t) lane;                  // (the word count: lanes of graphs of different lengths do not line up)
+    for (int k = 0; k < 4; ++k) { h = (h ^ hl[k]) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h2 = (h2 + h2l[k]) * 0xD6E8FEB86659FD93ull; h2 ^= h2 >> 32; }
     if (second) *second = h2;
     return h;
 }
