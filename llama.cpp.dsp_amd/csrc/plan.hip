@@ -1603,7 +1603,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             }
             if (first) { p.x_out = in.x_out; if (in.x_out) { OutRange xr = { in.x_out, in.k, (size_t) -1, 0, -1 }; outs.push_back(xr); } }
             {   // one plain vector of whole 256-element spans: the direct gather + quantize form (MI355Q_PLAN_DIRECT=0 turns it off: A/B measurements)
-                static const bool no_direct = getenv("MI355Q_PLAN_DIRECT") && atoi(getenv("MI355Q_PLAN_DIRECT")) == 0;
+                const bool no_direct = getenv("MI355Q_PLAN_DIRECT") && atoi(getenv("MI355Q_PLAN_DIRECT")) == 0;
                 if (first && !no_direct && in.x_kind == MI355Q_X_PLAIN && !in.x1 && in.k % 256 == 0) p.flags |= PLAN_F_DIRECT;
             }
             if (paired) { rows = in.mats[0].m; p.total_rows = (int) rows; p.flags |= PLAN_F_PAIRED; p.x_unary |= in.y_unary << 8; }   // per-workgroup PAIRS; the granule block holds m elements
@@ -1619,7 +1619,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
             first = false;
         }
         {   // sub-stages of different weight types -> one GROUP on disjoint workgroup ranges, sized by weight bytes (MI355Q_PLAN_GROUPS=0: one after the other)
-            static const bool no_groups = getenv("MI355Q_PLAN_GROUPS") && atoi(getenv("MI355Q_PLAN_GROUPS")) == 0;
+            const bool no_groups = getenv("MI355Q_PLAN_GROUPS") && atoi(getenv("MI355Q_PLAN_GROUPS")) == 0;
             const size_t n_sub = v.size() - first_sub;
             if (n_sub > 1 && !no_groups && (int) n_sub <= n_cu) {
                 double tot = 0; std::vector<double> wb(n_sub);
@@ -1642,7 +1642,7 @@ int mi355q_regs_plan_create(mi355q_plan ** out, const mi355q_stage * stages, int
     }
     if (set == 0) { mi355q_set_error("plan_create: a plan needs at least one GEMV stage"); return MI355Q_ERR_UNSUPPORTED; }
     {   // the stage that consumes an attention output (wo) runs on the workgroups that did NOT run the attention (MI355Q_PLAN_WO_SKIP=0: on all)
-        static const bool no_skip = getenv("MI355Q_PLAN_WO_SKIP") && atoi(getenv("MI355Q_PLAN_WO_SKIP")) == 0;
+        const bool no_skip = getenv("MI355Q_PLAN_WO_SKIP") && atoi(getenv("MI355Q_PLAN_WO_SKIP")) == 0;
         for (size_t si = 1; si < v.size() && !no_skip; ++si) {
             PlanStage & p = v[si];
             if (p.kind != PLAN_K_GEMV || p.group != 1 || p.wg_count != n_cu || (p.flags & PLAN_F_PAIRED) || v[si - 1].kind == PLAN_K_GEMV) continue;

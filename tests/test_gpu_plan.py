@@ -97,12 +97,13 @@ def test_norm_and_unary_prologues_match_the_node_ops(G, torch, t):
 
 
 @pytest.mark.parametrize("t", [oracle.Q4_K, oracle.Q6_K, oracle.Q8_0], ids=lambda t: oracle.TYPE_NAMES[t])
-@pytest.mark.parametrize("F", [4096, 1000, 14336], ids=str)
+@pytest.mark.parametrize("F", [4096, 1000, 14336, 4352, 10007], ids=str)
 def test_paired_output_unary_mul(G, torch, t, F):
     """MI355Q_Y_UNARY_MUL: the gate | up stage publishes SiLU(W_gate x) * (W_up x) itself (every workgroup computes matching rows of both
     matrices) and ffn_down gathers that one vector: bit-identical to mul_mat, mul_mat, op_unary_mul, mul_mat.  F = 1000: rows that do not
     divide by the workgroup count (ragged pair ranges, idle workgroups); F = 14336: 56 pairs per workgroup, i.e. 4 pairs on half of the waves and 3 on
-    the others (a wave streams the two rows of a pair back to back and publishes the product from its registers)."""
+    the others (a wave streams the two rows of a pair back to back and publishes the product from its registers).  F = 4352: 17 pairs, one wave with two;
+    F = 10007: 40 pairs per workgroup and a ragged last workgroup of 7."""
     rng = np.random.default_rng(60 + t + F)
     E = 2048
     w_g, w_u = W(G, t, F, E, rng), W(G, t, F, E, rng)
